@@ -1,0 +1,108 @@
+"""Pin the CPU oracle (oracle/postprocess.py) to the reference-generated golden
+vectors (tests/golden/make_golden.py) and to SURVEY.md 8c's known answers K1..K5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess as O
+
+# The fixtures were generated with one intra-op thread; torch's float32 mean/sum
+# order (hence the last bit) depends on the thread count, so pin it here too.
+torch.set_num_threads(1)
+
+P = O.PostParams()
+LEAVES = ["k1", "noise_burst", "short_loud", "tiny", "all_zero", "quiet", "edge_thresh", "ragged", "loud_to_end"]
+JOINS = ["k3_2", "k3_3", "mixed_5", "short_mid", "tiny_overlap", "silent_mid"]
+LOUD = ["k4", "k5", "gap", "rising", "exact_2w", "just_over", "hot", "near_silent"]
+
+
+def test_constants():
+    assert (P.window, P.hop, P.fade, P.crossfade, P.pause, P.loud_window) == (240, 120, 480, 1200, 2400, 48000)
+    assert P.threshold == 0.0031622776601683794
+
+
+@pytest.mark.parametrize("name", LEAVES)
+def test_leaves_bit_exact(golden_post, name):
+    g = golden_post
+    x = g[f"leaf/{name}/x"]
+    for tag, fs, fe in (("both", True, True), ("start", True, False), ("end", False, True)):
+        y = O.trim_silence(x, P, fs, fe).numpy()
+        assert y.shape[0] == g[f"leaf/{name}/trim_{tag}"].shape[0]
+        assert np.array_equal(y, g[f"leaf/{name}/trim_{tag}"])
+    assert np.array_equal(O.remove_dc(x).numpy(), g[f"leaf/{name}/dc"])
+    assert np.array_equal(O.apply_fades(x, P).numpy(), g[f"leaf/{name}/fades"])
+    assert np.array_equal(O.apply_fades(x, P, True, False).numpy(), g[f"leaf/{name}/fade_in_only"])
+    r, ok = O.sound_decay(x, P)
+    assert (r, float(ok)) == tuple(g[f"leaf/{name}/decay"])
+    assert np.array_equal(O.join_segments([x], P).numpy(), g[f"leaf/{name}/join1"])
+    assert np.array_equal(O.loudness_post_process(x, P).numpy(), g[f"leaf/{name}/post"])
+    assert np.array_equal(O.frame_energy(x, P).numpy(), g[f"leaf/{name}/energy"])
+
+
+@pytest.mark.parametrize("name", ["k1", "noise_burst", "tiny", "edge_thresh", "quiet"])
+def test_sequential_energy_is_bit_identical_to_avg_pool(golden_post, name):
+    """The explicit per-frame loop (what the HIP kernel runs) == ATen avg_pool1d, bit for bit."""
+    x = golden_post[f"leaf/{name}/x"][:6000]
+    msq, a = O.frame_energy_sequential(x, P)
+    sq = (torch.from_numpy(x) ** 2)[None]
+    ref_msq = torch.nn.functional.avg_pool1d(sq, P.window, P.hop, P.hop)[0].numpy()
+    assert msq.shape == ref_msq.shape and np.array_equal(msq, ref_msq)
+    b = O.frame_energy(x, P).numpy()
+    assert np.all(np.abs(a - b) <= np.spacing(np.maximum(a, b)))   # ATen's CPU sqrt is not correctly rounded
+
+
+@pytest.mark.parametrize("name", JOINS)
+def test_joins_bit_exact(golden_post, name):
+    g = golden_post
+    n = int(g[f"join/{name}/n"][0])
+    segs = [g[f"join/{name}/seg{i}"] for i in range(n)]
+    y, r, ok = O.finish_item(segs, P, loudness=False)
+    assert np.array_equal(y.numpy(), g[f"join/{name}/y"])
+    y2, r, ok = O.finish_item(segs, P, loudness=True)
+    assert np.array_equal(y2.numpy(), g[f"join/{name}/y_post"])
+    assert (r, float(ok)) == tuple(g[f"join/{name}/decay"])
+
+
+@pytest.mark.parametrize("name", LOUD)
+def test_loudness_bit_exact(golden_post, name):
+    g = golden_post
+    x = g[f"loud/{name}/x"]
+    y = O.loudness_post_process(x, P)
+    assert np.array_equal(y.numpy(), g[f"loud/{name}/y"])
+    r0, _ = O.sound_decay(x, P)
+    r1, ok1 = O.sound_decay(y, P)
+    assert (r0, r1, float(ok1)) == tuple(g[f"loud/{name}/decay"])
+
+
+def test_known_answers_survey_8c(golden_post):
+    g = golden_post
+    k1 = g["leaf/k1/x"]
+    assert O.trim_silence(k1, P).shape[0] == 24240                    # K1
+    assert O.trim_silence(k1, P, False, True).shape[0] == 36240
+    assert O.trim_silence(k1, P, True, False).shape[0] == 36000
+    assert O.trim_silence(np.zeros(24000, np.float32), P).shape[0] == 240
+    j = O.join_segments([k1], P)                                         # K2
+    assert j.shape[0] == 24240 and j[0] == 0 and abs(float(j[-1])) < 1e-12
+    assert abs(float(j.double().abs().sum()) - 4530.020948) < 1e-3
+    segs = [g[f"join/k3_3/seg{i}"] for i in range(3)]                   # K3
+    assert O.join_segments(segs[:2], P).shape[0] == 51840
+    y = O.join_segments(segs, P)
+    assert y.shape[0] == 77280
+    z = (y == 0).numpy()
+    assert z[48480:50880].all() and not z[48479] and not z[50880]
+    assert abs(float(y.double().abs().sum()) - 13364.681256) < 1e-3
+    k4 = g["loud/k4/x"]                                                  # K4
+    assert abs(O.sound_decay(k4, P)[0] - 0.393182) < 1e-6
+    o = O.loudness_post_process(k4, P)
+    rms_db = 20 * np.log10(float(torch.sqrt(torch.mean(o ** 2))))
+    assert abs(rms_db + 23.0246) < 1e-3 and abs(float(o.abs().max()) - 0.10807) < 1e-4
+    assert abs(O.sound_decay(o, P)[0] - 0.986270) < 1e-5
+    assert abs(float(o.double().abs().sum()) - 15205.4942) < 1e-2
+    o5 = O.loudness_post_process(g["loud/k5/x"], P)                     # K5
+    assert abs(20 * np.log10(float(torch.sqrt(torch.mean(o5 ** 2)))) + 23.0241) < 1e-3
+    assert abs(float(o5.abs().max()) - 0.09975) < 1e-4
+
+
+def test_pcm16_truncates():
+    x = np.array([0.0, 0.5, -0.5, 1.5, -1.5, 0.99999], np.float32)
+    assert O.pcm16(x).tolist() == [0, 16383, -16383, 32767, -32767, 32766]
