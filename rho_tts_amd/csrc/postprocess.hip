@@ -1,0 +1,512 @@
+// Fused audio post-processing for gfx950: one 1024-thread workgroup per text item runs the
+// whole per-item tail of the reference pipeline in ONE launch for the whole batch
+//   trim bounds -> DC removal -> (equal-power crossfade join, pauses) -> end fades
+//   -> 2-s windowed loudness correction -> -23 dBFS -> tanh soft clip -> decay ratio
+// Reference behaviour followed (paths relative to /root/reference/src/rho_tts/):
+//   base_tts.py:348-392, 394-399, 401-433, 435-536, 297-323; providers/qwen.py:268-378.
+//
+// Roofline: HBM streaming, 12 B/sample algorithmic (two reads + one write); the serial
+// dependency chain of five global reductions is kept inside the workgroup (barriers instead of
+// launches), samples are re-read from L2.  Arithmetic type: f32 samples, f64 reductions.
+//
+// Exactness contract (tests/test_post_gpu.py): integer outputs (trim bounds, lengths, flags)
+// are exact — the frame mean-square is accumulated in f32 in sample order with contraction off,
+// which is bit-identical to ATen's avg_pool1d on CPU — samples agree to 2e-6 absolute.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+
+struct SegDesc {
+    const float* x;
+    int64_t n;
+    uint32_t trim;  // RT_POST_TRIM_* for this segment (leaf calls / single-segment items)
+    uint32_t pad;
+};
+struct ItemDesc {
+    int32_t first_seg;
+    int32_t n_seg;
+    float* out;
+    int64_t out_cap;
+    double* gains;  // scratch for per-window gains, capacity out_cap / loud_window + 2
+};
+struct SegWork {
+    int64_t start, end;
+    float dc;
+    int32_t silent;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum_f64(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) t += sh[i];
+    return t;
+}
+
+// torch.linspace(a, b, n)[i] in float32 (ATen RangeFactories: symmetric two-sided evaluation)
+__device__ __forceinline__ float linspace_f32(float a, float b, int n, int i) {
+    if (n <= 1) return a;
+    const float step = (b - a) / (float)(n - 1);
+    return (i < n / 2) ? __fadd_rn(a, __fmul_rn(step, (float)i)) : __fsub_rn(b, __fmul_rn(step, (float)(n - 1 - i)));
+}
+
+__device__ __forceinline__ double sumsq_range(const float* p, int64_t lo, int64_t hi) {
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const double v = (double)p[i];
+        acc += v * v;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kThreads) void k_post_item(rt_post_params P, const ItemDesc* __restrict__ items,
+                                                        const SegDesc* __restrict__ segs, SegWork* __restrict__ work,
+                                                        rt_post_stats* __restrict__ stats) {
+    __shared__ double sh_red[kWaves];
+    __shared__ int sh_first, sh_last, sh_flag;
+    __shared__ double sh_bcast[4];
+
+    const ItemDesc it = items[blockIdx.x];
+    const int k = it.n_seg;
+    const SegDesc* sg = segs + it.first_seg;
+    SegWork* wk = work + it.first_seg;
+    float* out = it.out;
+    const uint32_t S = P.stages;
+    const bool join = (S & RT_POST_JOIN) && k > 1;
+    const int tid = threadIdx.x;
+
+    rt_post_stats st;
+    st.out_len = 0;
+    st.first_trim_start = 0;
+    st.first_trim_end = 0;
+    st.decay_ratio = 1.0;
+    st.rms_out = 0.0;
+    st.decay_ok = 1;
+    st.all_silent = 0;
+    st.fallback_concat = 0;
+    st.windowed_applied = 0;
+
+    // ------------------------------------------------------------ A: trim bounds
+    int n_silent = 0;
+    for (int s = 0; s < k; ++s) {
+        const float* x = sg[s].x;
+        const int64_t n = sg[s].n;
+        uint32_t tf;
+        if (join) tf = (s == 0) ? RT_POST_TRIM_END : (s == k - 1) ? RT_POST_TRIM_START : (RT_POST_TRIM_START | RT_POST_TRIM_END);
+        else tf = sg[s].trim & (RT_POST_TRIM_START | RT_POST_TRIM_END);
+        const bool do_trim = P.trim_enabled && n > 0 && tf != 0;
+        if (tid == 0) { sh_first = 0x7fffffff; sh_last = -1; }
+        __syncthreads();
+        if (do_trim) {
+            const int W = P.window, H = P.window / 2;
+            int64_t nf = (n + 2 * (int64_t)H - W) / H + 1;
+            if (nf < 1) nf = 1;
+            const float fw = (float)W;
+            int my_first = 0x7fffffff, my_last = -1;
+            for (int64_t f = tid; f < nf; f += kThreads) {
+                int64_t lo = f * H - H, hi = lo + W;
+                if (lo < 0) lo = 0;
+                if (hi > n) hi = n;
+                float acc = 0.0f;
+                for (int64_t i = lo; i < hi; ++i) {
+                    const float v = x[i];
+                    acc = __fadd_rn(acc, __fmul_rn(v, v));  // same order and rounding as ATen avg_pool1d (CPU)
+                }
+                const float e = __fsqrt_rn(__fdiv_rn(acc, fw));
+                if (e > P.silence_threshold) {
+                    if ((int)f < my_first) my_first = (int)f;
+                    if ((int)f > my_last) my_last = (int)f;
+                }
+            }
+            if (my_last >= 0) { atomicMin(&sh_first, my_first); atomicMax(&sh_last, my_last); }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int64_t a = 0, b = n;
+            int silent = 0;
+            if (do_trim) {
+                if (sh_last < 0) {  // nothing above threshold: keep one window (base_tts.py:379-380)
+                    a = 0; b = n < P.window ? n : P.window; silent = 1;
+                } else {
+                    if (tf & RT_POST_TRIM_START) a = (int64_t)sh_first * P.window / 2;
+                    if (tf & RT_POST_TRIM_END) b = ((int64_t)sh_last + 2) * P.window / 2;
+                    if (a > n) a = n;
+                    if (b > n) b = n;
+                    if (b < a) b = a;
+                }
+            }
+            wk[s].start = a; wk[s].end = b; wk[s].dc = 0.0f; wk[s].silent = silent;
+        }
+        __syncthreads();
+        n_silent += wk[s].silent;
+    }
+    st.all_silent = (k > 0 && n_silent == k) ? 1 : 0;
+    // Reference quirk: all-silent segment mixed with others => torch.cat of 1-D and 2-D raises and the
+    // reference concatenates the ORIGINAL segments (base_tts.py:530-533).
+    const bool fallback = join && n_silent > 0 && n_silent < k;
+    st.fallback_concat = fallback ? 1 : 0;
+    if (fallback) {
+        if (tid == 0) for (int s = 0; s < k; ++s) { wk[s].start = 0; wk[s].end = sg[s].n; wk[s].silent = 0; }
+        __syncthreads();
+    }
+    if (k > 0) { st.first_trim_start = wk[0].start; st.first_trim_end = wk[0].end; }
+
+    // ------------------------------------------------------------ B: DC offset per segment
+    if ((S & RT_POST_DC) && !fallback) {
+        for (int s = 0; s < k; ++s) {
+            const int64_t a = wk[s].start, b = wk[s].end;
+            double acc = 0.0;
+            for (int64_t i = a + tid; i < b; i += kThreads) acc += (double)sg[s].x[i];
+            const double tot = block_sum(acc, sh_red);
+            if (tid == 0) wk[s].dc = (b > a) ? (float)(tot / (double)(b - a)) : 0.0f;
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------ C: assemble into out
+    int64_t L = 0;
+    if (!join) {
+        // leaf call / single segment: out = x[start:end] - dc
+        if (k >= 1) {
+            const int64_t a = wk[0].start, b = wk[0].end;
+            const float dc = wk[0].dc;
+            const float* x = sg[0].x;
+            for (int64_t i = tid; i < b - a; i += kThreads) out[i] = __fsub_rn(x[a + i], dc);
+            L = b - a;
+        }
+    } else if (fallback) {
+        for (int s = 0; s < k; ++s) {
+            const float* x = sg[s].x;
+            for (int64_t i = tid; i < sg[s].n; i += kThreads) out[L + i] = x[i];
+            L += sg[s].n;
+        }
+    } else {
+        const int64_t XF = P.crossfade;
+        const float half_pi = (float)1.5707963267948966;
+        for (int s = 0; s < k; ++s) {
+            const float* x = sg[s].x + wk[s].start;
+            const int64_t Ls = wk[s].end - wk[s].start;
+            const float dc = wk[s].dc;
+            if (s == 0) {
+                const int64_t body = (Ls > XF) ? Ls - XF : Ls;  // base_tts.py:485-488
+                for (int64_t i = tid; i < body; i += kThreads) out[L + i] = __fsub_rn(x[i], dc);
+                L += body;
+                continue;
+            }
+            const float* xp = sg[s - 1].x + wk[s - 1].start;
+            const int64_t Lp = wk[s - 1].end - wk[s - 1].start;
+            const float dcp = wk[s - 1].dc;
+            int64_t ov = XF < Lp ? XF : Lp;
+            if (Ls < ov) ov = Ls;
+            if (ov > 10) {
+                for (int64_t j = tid; j < ov; j += kThreads) {
+                    const float down = cosf(linspace_f32(0.0f, half_pi, (int)ov, (int)j));
+                    const float up = cosf(linspace_f32(half_pi, 0.0f, (int)ov, (int)j));
+                    const float a = __fmul_rn(__fsub_rn(xp[Lp - ov + j], dcp), down);
+                    const float b = __fmul_rn(__fsub_rn(x[j], dc), up);
+                    out[L + j] = __fadd_rn(a, b);
+                }
+                L += ov;
+                int64_t rest_end = Ls;
+                if (s < k - 1 && Ls > ov + XF) rest_end = Ls - XF;  // base_tts.py:507-513
+                for (int64_t i = ov + tid; i < rest_end; i += kThreads) out[L + (i - ov)] = __fsub_rn(x[i], dc);
+                L += rest_end - ov;
+                if (P.pause > 0 && s < k - 1) {
+                    for (int64_t i = tid; i < P.pause; i += kThreads) out[L + i] = 0.0f;
+                    L += P.pause;
+                }
+            } else {
+                for (int64_t i = tid; i < Ls; i += kThreads) out[L + i] = __fsub_rn(x[i], dc);
+                L += Ls;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ C2: end fades (base_tts.py:420-431)
+    {
+        const int F = P.fade;
+        if (L > 0 && L >= 2 * (int64_t)F && F > 0) {
+            const float pi_f = (float)3.141592653589793;
+            if (S & RT_POST_FADE_IN)
+                for (int i = tid; i < F; i += kThreads) {
+                    const float c = __fmul_rn(0.5f, __fsub_rn(1.0f, cosf(linspace_f32(0.0f, pi_f, F, i))));
+                    out[i] = __fmul_rn(out[i], c);
+                }
+            __syncthreads();  // L == 2F: the two ramps touch disjoint halves, but keep the order fixed
+            if (S & RT_POST_FADE_OUT)
+                for (int i = tid; i < F; i += kThreads) {
+                    const float c = __fmul_rn(0.5f, __fadd_rn(1.0f, cosf(linspace_f32(0.0f, pi_f, F, i))));
+                    out[L - F + i] = __fmul_rn(out[L - F + i], c);
+                }
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------ D: loudness (qwen.py:268-378)
+    if ((S & RT_POST_LOUDNESS) && L > 0) {
+        const double tot0 = block_sum(sumsq_range(out, 0, L), sh_red);
+        const float rms0 = __fsqrt_rn((float)(tot0 / (double)L));
+        if (!(rms0 < 1e-8f)) {
+            const int64_t W = P.loud_window;
+            int apply_env = 0;
+            int64_t nw = 0;
+            if (W > 0 && L > 2 * W) {
+                nw = L / W;
+                double* g = it.gains;
+                // per-window RMS: one wave per window, round-robin
+                const int wv = tid >> 6, ln = tid & 63;
+                for (int64_t w = wv; w < nw; w += kWaves) {
+                    double acc = 0.0;
+                    const float* p = out + w * W;
+                    for (int64_t i = ln; i < W; i += 64) { const double v = (double)p[i]; acc += v * v; }
+                    acc = wave_sum_f64(acc);
+                    if (ln == 0) g[w] = (double)__fsqrt_rn((float)(acc / (double)W));
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int ok = 0;
+                    const double ref = g[0];
+                    if (nw >= 2 && !(ref < 1e-8)) {
+                        const double cap = pow(10.0, P.max_gain_db / 20.0);
+                        double mx = -1e300, mn = 1e300;
+                        for (int64_t w = 0; w < nw; ++w) {
+                            const double r = g[w];
+                            double gn = 1.0;
+                            if (!(r < 1e-8)) { gn = ref / r; if (gn > cap) gn = cap; }
+                            g[w] = gn;
+                            mx = gn > mx ? gn : mx;
+                            mn = gn < mn ? gn : mn;
+                        }
+                        if (!(mx - mn < 0.05)) {
+                            ok = 1;
+                            // two passes of a 3-tap mean over interior points (qwen.py:365-370), in place with carries
+                            for (int pass = 0; pass < 2; ++pass) {
+                                double prev = g[0];
+                                for (int64_t w = 1; w + 1 < nw; ++w) {
+                                    const double cur = g[w];
+                                    g[w] = (prev + cur + g[w + 1]) / 3;
+                                    prev = cur;
+                                }
+                            }
+                        }
+                    }
+                    sh_flag = ok;
+                }
+                __syncthreads();
+                apply_env = sh_flag;
+            }
+            st.windowed_applied = apply_env;
+
+            // envelope (np.interp in f64 over window centres) fused with the global sum of squares
+            double acc = 0.0;
+            if (apply_env) {
+                const double* g = it.gains;
+                const double Wd = (double)W;
+                const double c0 = 0.5 * Wd, cN = ((double)(nw - 1) + 0.5) * Wd;
+                for (int64_t i = tid; i < L; i += kThreads) {
+                    const double xi = (double)i;
+                    double e;
+                    if (xi <= c0) e = g[0];
+                    else if (xi >= cN) e = g[nw - 1];
+                    else {
+                        int64_t j = (int64_t)floor(xi / Wd - 0.5);
+                        if (j < 0) j = 0;
+                        if (j > nw - 2) j = nw - 2;
+                        const double xj = ((double)j + 0.5) * Wd;
+                        const double slope = (g[j + 1] - g[j]) / Wd;
+                        e = slope * (xi - xj) + g[j];
+                    }
+                    const float v = __fmul_rn(out[i], (float)e);
+                    out[i] = v;
+                    acc += (double)v * (double)v;
+                }
+            } else {
+                acc = sumsq_range(out, 0, L);
+            }
+            const double tot1 = block_sum(acc, sh_red);
+            const float rms1 = __fsqrt_rn((float)(tot1 / (double)L));
+            float gain = 1.0f;
+            if (rms1 > 1e-8f) {
+                const double cur_db = (double)__fmul_rn(20.0f, log10f(rms1));
+                gain = (float)pow(10.0, (P.target_rms_db - cur_db) / 20.0);
+            }
+            const float amp = (float)P.max_amplitude;
+            for (int64_t i = tid; i < L; i += kThreads) {
+                float v = out[i];
+                if (rms1 > 1e-8f) v = __fmul_rn(v, gain);
+                out[i] = __fmul_rn(tanhf(__fdiv_rn(v, amp)), amp);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------ E: statistics
+    {
+        const double tot = block_sum(sumsq_range(out, 0, L), sh_red);
+        st.rms_out = L > 0 ? sqrt(tot / (double)L) : 0.0;
+    }
+    if (S & RT_POST_DECAY) {
+        const int64_t third = L / 3;
+        if (L > 0 && third >= 1) {
+            const double s1 = block_sum(sumsq_range(out, 0, third), sh_red);
+            const double s2 = block_sum(sumsq_range(out, L - third, L), sh_red);
+            const double r1 = (double)__fsqrt_rn((float)(s1 / (double)third));
+            const double r2 = (double)__fsqrt_rn((float)(s2 / (double)third));
+            if (!(r1 < 1e-8)) {
+                st.decay_ratio = r2 / r1;
+                st.decay_ok = st.decay_ratio >= P.decay_threshold ? 1 : 0;
+            }
+        }
+    }
+    st.out_len = L;
+    if (tid == 0) stats[blockIdx.x] = st;
+    (void)sh_bcast;
+}
+
+__global__ void k_pcm16(const float* __restrict__ in, int64_t n, int16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = in[i];
+        v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+        out[i] = (int16_t)__fmul_rn(v, 32767.0f);  // C cast truncates toward zero, like numpy astype(int16)
+    }
+}
+
+int post_impl(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32_t* first, const float* const* seg_ptr,
+              const int64_t* seg_len, const uint8_t* seg_trim, float* const* out_ptr, const int64_t* out_cap,
+              rt_post_stats* h_stats, bool host_buffers) {
+    if (!ctx || !p || n_items < 0 || (n_items > 0 && (!first || !seg_ptr || !seg_len || !out_ptr || !out_cap || !h_stats)))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: null argument");
+    if (n_items == 0) return RT_OK;
+    if (p->window < 2 || p->fade < 0 || p->crossfade < 0 || p->pause < 0 || p->sample_rate <= 0)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: bad geometry (window=%d fade=%d)", p->window, p->fade);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_seg = first[n_items];
+    if (first[0] != 0 || n_seg < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: item_first_seg must start at 0");
+    int64_t tot_in = 0, tot_out = 0, tot_gain = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const int k = first[i + 1] - first[i];
+        if (k < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: item_first_seg not monotone");
+        if (k > 1 && !(p->stages & RT_POST_JOIN))
+            return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: item %d has %d segments but RT_POST_JOIN is not set", i, k);
+        const int64_t need = rt_post_capacity(p, k, seg_len + first[i]);
+        if (out_cap[i] < need)
+            return rt_fail(ctx, RT_ERR_LENGTH, "rt_post_process: output length capacity %lld < %lld for item %d",
+                           (long long)out_cap[i], (long long)need, i);
+        tot_out += out_cap[i];
+        tot_gain += (p->loud_window > 0 ? out_cap[i] / p->loud_window : 0) + 2;
+    }
+    for (int s = 0; s < n_seg; ++s) {
+        if (seg_len[s] < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: negative segment length");
+        tot_in += seg_len[s];
+    }
+
+    // device scratch layout: [items][segs][work][stats][gains][(host mode) in samples][(host mode) out samples]
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_items = 0;
+    const size_t o_segs = al(o_items + sizeof(ItemDesc) * n_items);
+    const size_t o_work = al(o_segs + sizeof(SegDesc) * (n_seg > 0 ? n_seg : 1));
+    const size_t o_stats = al(o_work + sizeof(SegWork) * (n_seg > 0 ? n_seg : 1));
+    const size_t o_gains = al(o_stats + sizeof(rt_post_stats) * n_items);
+    const size_t o_in = al(o_gains + sizeof(double) * tot_gain);
+    const size_t o_out = al(o_in + (host_buffers ? sizeof(float) * tot_in : 0));
+    const size_t total = al(o_out + (host_buffers ? sizeof(float) * tot_out : 0));
+    void* dv = nullptr;
+    int rc = rt_ctx_scratch(ctx, total, &dv);
+    if (rc) return rc;
+    char* d = (char*)dv;
+    void* hv = nullptr;
+    const size_t h_desc = o_work;  // items + segs
+    rc = rt_ctx_pinned(ctx, h_desc + sizeof(rt_post_stats) * n_items, &hv);
+    if (rc) return rc;
+    char* h = (char*)hv;
+    ItemDesc* hi = (ItemDesc*)(h + o_items);
+    SegDesc* hs = (SegDesc*)(h + o_segs);
+    const uint32_t leaf_trim = p->stages & (RT_POST_TRIM_START | RT_POST_TRIM_END);
+    int64_t in_off = 0, out_off = 0, gain_off = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        hs[s].n = seg_len[s];
+        hs[s].trim = seg_trim ? (uint32_t)seg_trim[s] : leaf_trim;
+        hs[s].pad = 0;
+        if (host_buffers) {
+            hs[s].x = (const float*)(d + o_in) + in_off;
+            if (seg_len[s] > 0)
+                RT_HIP(ctx, hipMemcpyAsync((void*)hs[s].x, seg_ptr[s], sizeof(float) * seg_len[s], hipMemcpyHostToDevice, ctx->stream));
+            in_off += seg_len[s];
+        } else {
+            hs[s].x = seg_ptr[s];
+        }
+    }
+    for (int i = 0; i < n_items; ++i) {
+        hi[i].first_seg = first[i];
+        hi[i].n_seg = first[i + 1] - first[i];
+        hi[i].out_cap = out_cap[i];
+        hi[i].out = host_buffers ? (float*)(d + o_out) + out_off : out_ptr[i];
+        hi[i].gains = (double*)(d + o_gains) + gain_off;
+        out_off += out_cap[i];
+        gain_off += (p->loud_window > 0 ? out_cap[i] / p->loud_window : 0) + 2;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(d, h, h_desc, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_post_item, dim3(n_items), dim3(kThreads), 0, ctx->stream, *p, (const ItemDesc*)(d + o_items),
+                       (const SegDesc*)(d + o_segs), (SegWork*)(d + o_work), (rt_post_stats*)(d + o_stats));
+    RT_HIP(ctx, hipGetLastError());
+    rt_post_stats* hst = (rt_post_stats*)(h + h_desc);
+    RT_HIP(ctx, hipMemcpyAsync(hst, d + o_stats, sizeof(rt_post_stats) * n_items, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h_stats, hst, sizeof(rt_post_stats) * n_items);
+    if (host_buffers) {
+        for (int i = 0; i < n_items; ++i)
+            if (h_stats[i].out_len > 0)
+                RT_HIP(ctx, hipMemcpyAsync(out_ptr[i], hi[i].out, sizeof(float) * h_stats[i].out_len, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rt_post_capacity(const rt_post_params* p, int32_t n_segments, const int64_t* h_seg_len) {
+    if (!p || n_segments < 0 || (n_segments > 0 && !h_seg_len)) return -1;
+    int64_t t = 0;
+    for (int i = 0; i < n_segments; ++i) t += h_seg_len[i] > 0 ? h_seg_len[i] : 0;
+    if (n_segments > 2) t += (int64_t)(n_segments - 2) * (p->pause > 0 ? p->pause : 0);
+    return t > 0 ? t : 1;
+}
+
+int rt_post_process(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32_t* h_item_first_seg,
+                    const float* const* h_seg_ptr, const int64_t* h_seg_len, const uint8_t* h_seg_trim,
+                    float* const* h_out_ptr, const int64_t* h_out_cap, rt_post_stats* h_stats) {
+    return post_impl(ctx, p, n_items, h_item_first_seg, h_seg_ptr, h_seg_len, h_seg_trim, h_out_ptr, h_out_cap, h_stats, false);
+}
+
+int rt_post_process_host(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32_t* h_item_first_seg,
+                         const float* const* h_seg_ptr, const int64_t* h_seg_len, const uint8_t* h_seg_trim,
+                         float* const* h_out_ptr, const int64_t* h_out_cap, rt_post_stats* h_stats) {
+    return post_impl(ctx, p, n_items, h_item_first_seg, h_seg_ptr, h_seg_len, h_seg_trim, h_out_ptr, h_out_cap, h_stats, true);
+}
+
+int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out) {
+    if (!ctx || n < 0 || (n > 0 && (!d_in || !d_out))) return rt_fail(ctx, RT_ERR_INVALID, "rt_pcm16: null argument");
+    if (n == 0) return RT_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_pcm16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_in, n, d_out);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+}  // extern "C"

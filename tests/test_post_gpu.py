@@ -1,0 +1,173 @@
+"""GPU parity of the fused post-processing kernel (through the C ABI) against the
+reference-generated golden vectors and the CPU oracle.
+
+Bar: integer outputs (trim bounds, lengths, flags) exact; samples within 2e-6
+absolute (float32 data in [-1, 1]; the differences are reduction order of the
+mean/RMS and libm-vs-device cos/tanh/log10); decay ratio within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+P = O.PostParams()
+LEAVES = ["k1", "noise_burst", "short_loud", "tiny", "all_zero", "quiet", "ragged", "loud_to_end"]
+JOINS = ["k3_2", "k3_3", "mixed_5", "short_mid", "tiny_overlap", "silent_mid"]
+LOUD = ["k4", "k5", "gap", "rising", "exact_2w", "just_over", "hot", "near_silent"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rho_tts_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def run(ctx, items, stages, device="cuda", seg_trim=None, **kw):
+    from rho_tts_amd import _native
+    p = _native.make_post_params(stages=stages, **kw)
+    tens = [[torch.from_numpy(np.ascontiguousarray(s)).to(device) for s in it] for it in items]
+    outs, stats = ctx.post_process(p, tens, seg_trim)
+    return [o.cpu().numpy() for o in outs], stats
+
+
+def close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size:
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max()
+        assert d <= tol, d
+
+
+@pytest.mark.parametrize("device", ["cuda", "cpu"])
+@pytest.mark.parametrize("name", LEAVES)
+def test_leaves_against_golden(ctx, golden_post, name, device):
+    from rho_tts_amd import _native as N
+    g = golden_post
+    x = g[f"leaf/{name}/x"]
+    for tag, st in (("both", N.POST_TRIM_START | N.POST_TRIM_END), ("start", N.POST_TRIM_START), ("end", N.POST_TRIM_END)):
+        (y,), (s,) = run(ctx, [[x]], st, device)
+        assert np.array_equal(y, g[f"leaf/{name}/trim_{tag}"])          # pure slicing: exact
+        assert bool(s.all_silent) == (len(g[f"leaf/{name}/trim_{tag}_shape"]) == 2)
+    (y,), _ = run(ctx, [[x]], N.POST_DC, device)
+    close(y, g[f"leaf/{name}/dc"])
+    (y,), _ = run(ctx, [[x]], N.POST_FADE_IN | N.POST_FADE_OUT, device)
+    close(y, g[f"leaf/{name}/fades"])
+    (y,), _ = run(ctx, [[x]], N.POST_FADE_IN, device)
+    close(y, g[f"leaf/{name}/fade_in_only"])
+    (y,), (s,) = run(ctx, [[x]], N.POST_DECAY, device)
+    assert np.array_equal(y, x)
+    r, ok = g[f"leaf/{name}/decay"]
+    assert abs(s.decay_ratio - r) <= 1e-5 * max(1.0, r) and bool(s.decay_ok) == bool(ok)
+    (y,), _ = run(ctx, [[x]], N.POST_TRIM_START | N.POST_TRIM_END | N.POST_DC | N.POST_FADE_IN | N.POST_FADE_OUT | N.POST_JOIN, device)
+    close(y, g[f"leaf/{name}/join1"])
+    (y,), _ = run(ctx, [[x]], N.POST_LOUDNESS, device)
+    close(y, g[f"leaf/{name}/post"])
+
+
+@pytest.mark.parametrize("name", JOINS)
+def test_joins_against_golden(ctx, golden_post, name):
+    from rho_tts_amd import _native as N
+    g = golden_post
+    n = int(g[f"join/{name}/n"][0])
+    segs = [g[f"join/{name}/seg{i}"] for i in range(n)]
+    st = N.POST_PIPELINE & ~(N.POST_LOUDNESS | N.POST_DECAY)
+    (y,), (s,) = run(ctx, [segs], st)
+    close(y, g[f"join/{name}/y"])
+    assert bool(s.fallback_concat) == (name == "silent_mid")
+    (y,), (s,) = run(ctx, [segs], N.POST_PIPELINE)
+    close(y, g[f"join/{name}/y_post"])
+    r, ok = g[f"join/{name}/decay"]
+    assert abs(s.decay_ratio - r) <= 1e-5 * max(1.0, r) and bool(s.decay_ok) == bool(ok)
+
+
+@pytest.mark.parametrize("name", LOUD)
+def test_loudness_against_golden(ctx, golden_post, name):
+    from rho_tts_amd import _native as N
+    g = golden_post
+    x = g[f"loud/{name}/x"]
+    (y,), (s,) = run(ctx, [[x]], N.POST_LOUDNESS | N.POST_DECAY)
+    close(y, g[f"loud/{name}/y"])
+    r0, r1, ok1 = g[f"loud/{name}/decay"]
+    assert abs(s.decay_ratio - r1) <= 1e-5 * max(1.0, r1) and bool(s.decay_ok) == bool(ok1)
+
+
+def test_whole_batch_in_one_launch_matches_per_item(ctx, golden_post):
+    """All golden items as ONE batch (one launch, one workgroup per item) == one call per item."""
+    from rho_tts_amd import _native as N
+    g = golden_post
+    items = [[g[f"leaf/{n}/x"]] for n in LEAVES]
+    items += [[g[f"join/{n}/seg{i}"] for i in range(int(g[f"join/{n}/n"][0]))] for n in JOINS]
+    items += [[g[f"loud/{n}/x"]] for n in LOUD]
+    ys, ss = run(ctx, items, N.POST_PIPELINE)
+    assert len(ys) == len(items)
+    for it, y, s in zip(items, ys, ss):
+        (y1,), (s1,) = run(ctx, [it], N.POST_PIPELINE)
+        assert np.array_equal(y, y1) and s.out_len == s1.out_len and s.decay_ratio == s1.decay_ratio
+        ref, r, ok = O.finish_item(it, P)
+        close(y, ref.numpy())
+        assert abs(s.decay_ratio - r) <= 1e-5 * max(1.0, r) and bool(s.decay_ok) == ok
+
+
+def test_seeded_random_batch_against_oracle(ctx):
+    from rho_tts_amd import _native as N
+    rng = np.random.default_rng(20240)
+    items = []
+    for i in range(24):
+        k = int(rng.integers(1, 5))
+        segs = []
+        for _ in range(k):
+            n = int(rng.integers(3000, 120000))
+            lead, tail = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))
+            body = rng.standard_normal(n).astype(np.float32) * np.float32(rng.uniform(0.02, 0.5))
+            env = np.linspace(1.0, rng.uniform(0.1, 1.0), n).astype(np.float32)
+            body = body * env + np.float32(rng.uniform(-0.02, 0.02))
+            segs.append(np.concatenate([np.zeros(lead, np.float32), body, 1e-5 * rng.standard_normal(tail).astype(np.float32)]))
+        items.append(segs)
+    ys, ss = run(ctx, items, N.POST_PIPELINE)
+    for it, y, s in zip(items, ys, ss):
+        ref, r, ok = O.finish_item(it, P)
+        close(y, ref.numpy())
+        assert s.out_len == ref.shape[0]
+        assert abs(s.decay_ratio - r) <= 1e-5 * max(1.0, r) and bool(s.decay_ok) == ok
+
+
+def test_full_size_properties(ctx):
+    """Ten minutes of audio (14.4 M samples): size-independent properties instead of an oracle run."""
+    from rho_tts_amd import _native as N
+    n = 24000 * 600
+    t = torch.arange(n, device="cuda", dtype=torch.float32)
+    x = 0.3 * torch.sin(t * (2 * np.pi * 220 / 24000)) * torch.linspace(1.0, 0.3, n, device="cuda") + 0.01
+    x[:24000] = 0
+    x[-36000:] = 0
+    p = N.make_post_params(stages=N.POST_PIPELINE)
+    (y,), (s,) = ctx.post_process(p, [[x]])
+    assert s.first_trim_start == 24000 - 120 and s.out_len == y.numel()
+    assert abs(s.first_trim_end - (n - 36000)) <= 240
+    rms_db = 20 * np.log10(float(torch.sqrt(torch.mean(y.double() ** 2))))
+    assert abs(rms_db + 23.0) < 0.1                        # -23 dBFS target (tanh shaves a little)
+    assert float(y.abs().max()) < 0.95                      # soft clip bound
+    assert abs(float(y[0])) < 1e-9 and abs(float(y[-1])) < 1e-6   # faded ends
+    assert s.windowed_applied == 1 and s.decay_ratio > 0.8  # decay corrected
+    # idempotence of the trim: trimming the output again removes nothing but the faded-out edge frames
+    (y2,), (s2,) = ctx.post_process(N.make_post_params(stages=N.POST_TRIM_START | N.POST_TRIM_END), [[y]])
+    assert y.numel() - y2.numel() <= 4 * 240
+
+
+def test_empty_and_error_paths(ctx):
+    from rho_tts_amd import _native as N
+    (y,), (s,) = run(ctx, [[np.zeros(0, np.float32)]], N.POST_PIPELINE)
+    assert y.shape == (0,) and s.out_len == 0 and s.decay_ratio == 1.0 and s.decay_ok == 1
+    with pytest.raises(ValueError):                          # >1 segment without JOIN is a configuration error
+        run(ctx, [[np.ones(10, np.float32), np.ones(10, np.float32)]], N.POST_DC)
+    x = np.ones(100, np.float32)
+    (y,), _ = run(ctx, [[x]], N.POST_TRIM_START | N.POST_TRIM_END, trim_silence=False)
+    assert np.array_equal(y, x)
+
+
+def test_pcm16(ctx):
+    x = torch.tensor([0.0, 0.5, -0.5, 1.5, -1.5, 0.99999], device="cuda")
+    assert ctx.pcm16(x).cpu().tolist() == O.pcm16(x.cpu()).tolist() == [0, 16383, -16383, 32767, -32767, 32766]
