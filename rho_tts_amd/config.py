@@ -1,0 +1,211 @@
+"""Shape description of a Qwen3-TTS-style model (talker + code predictor + codec decoder).
+
+The reference never spells these numbers out: the model lives in the third-party
+``qwen-tts`` package (reference call sites providers/qwen.py:100,160-165,247-258)
+and no ``config.json`` is available offline.  Everything here is therefore a
+parameter; the named presets carry the dimensions SURVEY.md section 8d assumes
+(marked UNVERIFIED there) and ``from_hf_config`` reads a real config when one is
+present in ``model_path``.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict, dataclass, field
+from typing import Dict, Tuple
+
+
+@dataclass
+class TransformerDims:
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    head_dim: int
+    inter: int
+    rope_theta: float = 1_000_000.0
+    rms_eps: float = 1e-6
+
+    @property
+    def q_dim(self) -> int:
+        return self.heads * self.head_dim
+
+    @property
+    def kv_dim(self) -> int:
+        return self.kv_heads * self.head_dim
+
+    def weight_params(self) -> int:
+        """Matrix parameters of the decoder layers (what a decode step streams)."""
+        per = self.hidden * (self.q_dim + 2 * self.kv_dim) + self.q_dim * self.hidden + 3 * self.hidden * self.inter
+        return self.layers * per
+
+
+@dataclass
+class CodecDims:
+    codebook_size: int = 2048
+    num_quantizers: int = 16
+    hidden: int = 1024
+    layers: int = 8
+    heads: int = 16
+    head_dim: int = 64
+    inter: int = 3072
+    sliding_window: int = 72
+    rope_theta: float = 10_000.0
+    rms_eps: float = 1e-5
+    layer_scale: float = 0.01
+    upsampling_ratios: Tuple[int, ...] = (2, 2)
+    upsample_rates: Tuple[int, ...] = (8, 5, 4, 3)
+    decoder_dim: int = 1536
+    chunk_frames: int = 300
+    left_context_frames: int = 25
+
+    @property
+    def total_upsample(self) -> int:
+        t = 1
+        for r in tuple(self.upsampling_ratios) + tuple(self.upsample_rates):
+            t *= r
+        return t
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    talker: TransformerDims
+    predictor: TransformerDims
+    codec: CodecDims = field(default_factory=CodecDims)
+    codec_vocab: int = 3072          # talker output vocabulary: 2048 codes + control ids
+    predictor_vocab: int = 2048
+    text_vocab: int = 151936
+    text_hidden: int = 2048
+    n_groups: int = 16
+    sample_rate: int = 24000
+    max_positions: int = 4096
+    # text-side control ids
+    tts_pad_id: int = 151671
+    tts_bos_id: int = 151672
+    tts_eos_id: int = 151673
+    role_ids: Tuple[int, ...] = (151644, 77091, 198)   # <|im_start|> assistant \n
+    # codec-side control ids (inside [codebook_size, codec_vocab))
+    codec_pad_id: int = 2148
+    codec_bos_id: int = 2149
+    codec_eos_id: int = 2150
+    codec_think_id: int = 2154
+    codec_nothink_id: int = 2155
+    codec_think_bos_id: int = 2156
+    codec_think_eos_id: int = 2157
+    language_ids: Dict[str, int] = field(default_factory=lambda: {
+        "english": 2050, "chinese": 2055, "japanese": 2058, "korean": 2064})
+    speaker_ids: Dict[str, int] = field(default_factory=lambda: {
+        n.lower(): 2200 + i for i, n in enumerate(
+            ["Chelsie", "Aidan", "Vivian", "Ryan", "Aria", "Ethan", "Luna", "Harper", "James"])})
+
+    @property
+    def frame_rate(self) -> float:
+        return self.sample_rate / self.codec.total_upsample
+
+    @property
+    def has_mtp_proj(self) -> bool:
+        return self.talker.hidden != self.predictor.hidden
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), indent=1)
+
+
+def qwen3_tts_1p7b() -> ModelConfig:
+    return ModelConfig(
+        name="Qwen3-TTS-1.7B",
+        talker=TransformerDims(hidden=2048, layers=28, heads=16, kv_heads=8, head_dim=128, inter=6144),
+        predictor=TransformerDims(hidden=1024, layers=5, heads=16, kv_heads=8, head_dim=128, inter=3072),
+        text_hidden=2048)
+
+
+def qwen3_tts_0p6b() -> ModelConfig:
+    return ModelConfig(
+        name="Qwen3-TTS-0.6B",
+        talker=TransformerDims(hidden=1024, layers=28, heads=16, kv_heads=8, head_dim=128, inter=3072),
+        predictor=TransformerDims(hidden=1024, layers=5, heads=16, kv_heads=8, head_dim=128, inter=3072),
+        text_hidden=2048)
+
+
+def tiny(name: str = "tiny") -> ModelConfig:
+    """A few-thousand-parameter model of the same topology for parity tests
+    (sizes chosen so every code path — GQA, mtp projection, multi-tile GEMMs,
+    all decoder stages — is exercised while the oracle runs in seconds)."""
+    return ModelConfig(
+        name=name,
+        talker=TransformerDims(hidden=128, layers=2, heads=4, kv_heads=2, head_dim=32, inter=256),
+        predictor=TransformerDims(hidden=64, layers=2, heads=2, kv_heads=1, head_dim=32, inter=128),
+        codec=CodecDims(codebook_size=64, num_quantizers=4, hidden=64, layers=2, heads=2, head_dim=32, inter=128,
+                        sliding_window=8, upsampling_ratios=(2,), upsample_rates=(3, 2), decoder_dim=64,
+                        chunk_frames=12, left_context_frames=3),
+        codec_vocab=128, predictor_vocab=64, text_vocab=512, text_hidden=96, n_groups=4, max_positions=256,
+        tts_pad_id=500, tts_bos_id=501, tts_eos_id=502, role_ids=(503, 504, 505),
+        codec_pad_id=70, codec_bos_id=71, codec_eos_id=72, codec_think_id=73, codec_nothink_id=74,
+        codec_think_bos_id=75, codec_think_eos_id=76,
+        language_ids={"english": 80, "chinese": 81, "japanese": 82, "korean": 83},
+        speaker_ids={"vivian": 90, "ryan": 91})
+
+
+def small(name: str = "small") -> ModelConfig:
+    """Mid-size topology (head_dim 128, MFMA-tile-aligned dims) used by GPU parity tests."""
+    return ModelConfig(
+        name=name,
+        talker=TransformerDims(hidden=512, layers=3, heads=8, kv_heads=4, head_dim=128, inter=1024),
+        predictor=TransformerDims(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=128, inter=512),
+        codec=CodecDims(codebook_size=256, num_quantizers=8, hidden=256, layers=2, heads=4, head_dim=64, inter=512,
+                        sliding_window=16, upsampling_ratios=(2, 2), upsample_rates=(4, 3, 2), decoder_dim=384,
+                        chunk_frames=24, left_context_frames=4),
+        codec_vocab=384, predictor_vocab=256, text_vocab=4096, text_hidden=320, n_groups=8, max_positions=1024,
+        tts_pad_id=4000, tts_bos_id=4001, tts_eos_id=4002, role_ids=(4003, 4004, 4005),
+        codec_pad_id=300, codec_bos_id=301, codec_eos_id=302, codec_think_id=303, codec_nothink_id=304,
+        codec_think_bos_id=305, codec_think_eos_id=306,
+        language_ids={"english": 310, "chinese": 311, "japanese": 312, "korean": 313},
+        speaker_ids={"vivian": 320, "ryan": 321})
+
+
+PRESETS = {"1.7b": qwen3_tts_1p7b, "0.6b": qwen3_tts_0p6b, "tiny": tiny, "small": small}
+
+
+def resolve(model_path: str) -> ModelConfig:
+    """Pick a config from a model id / path the way the reference's users name models
+    (``Qwen/Qwen3-TTS-12Hz-1.7B-Base``, providers/qwen.py:57; UI catalogue ui/config.py:33-60)."""
+    cfg_file = os.path.join(model_path, "config.json") if os.path.isdir(model_path) else None
+    if cfg_file and os.path.exists(cfg_file):
+        return from_hf_config(json.load(open(cfg_file)), name=os.path.basename(model_path.rstrip("/")))
+    low = model_path.lower()
+    for key in ("tiny", "small"):
+        if low.endswith(key):
+            return PRESETS[key]()
+    if "0.6b" in low:
+        return qwen3_tts_0p6b()
+    return qwen3_tts_1p7b()
+
+
+def _dims(d: dict, default: TransformerDims) -> TransformerDims:
+    return TransformerDims(
+        hidden=d.get("hidden_size", default.hidden), layers=d.get("num_hidden_layers", default.layers),
+        heads=d.get("num_attention_heads", default.heads), kv_heads=d.get("num_key_value_heads", default.kv_heads),
+        head_dim=d.get("head_dim", default.head_dim), inter=d.get("intermediate_size", default.inter),
+        rope_theta=float(d.get("rope_theta", default.rope_theta)), rms_eps=float(d.get("rms_norm_eps", default.rms_eps)))
+
+
+def from_hf_config(js: dict, name: str = "hf") -> ModelConfig:
+    """Best-effort reader of a Hugging Face style ``config.json`` (talker_config /
+    code_predictor_config sub-dicts as in the Qwen3-Omni sibling architecture,
+    transformers/models/qwen3_omni_moe/configuration_qwen3_omni_moe.py)."""
+    base = qwen3_tts_1p7b()
+    t = js.get("talker_config", js)
+    p = t.get("code_predictor_config", js.get("code_predictor_config", {}))
+    cfg = ModelConfig(name=name, talker=_dims(t.get("text_config", t), base.talker), predictor=_dims(p, base.predictor))
+    cfg.codec_vocab = t.get("vocab_size", cfg.codec_vocab)
+    cfg.predictor_vocab = p.get("vocab_size", cfg.predictor_vocab)
+    cfg.n_groups = t.get("num_code_groups", cfg.n_groups)
+    cfg.text_vocab = t.get("text_vocab_size", cfg.text_vocab)
+    cfg.text_hidden = t.get("text_hidden_size", cfg.text_hidden)
+    for k in ("codec_pad_id", "codec_bos_id", "codec_eos_id", "codec_think_id", "codec_nothink_id",
+              "codec_think_bos_id", "codec_think_eos_id"):
+        if k in t:
+            setattr(cfg, k, t[k])
+    if "codec_eos_token_id" in t:
+        cfg.codec_eos_id = t["codec_eos_token_id"]
+    return cfg

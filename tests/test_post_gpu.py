@@ -145,7 +145,7 @@ def test_full_size_properties(ctx):
     x[-36000:] = 0
     p = N.make_post_params(stages=N.POST_PIPELINE)
     (y,), (s,) = ctx.post_process(p, [[x]])
-    assert s.first_trim_start == 24000 - 120 and s.out_len == y.numel()
+    assert abs(s.first_trim_start - 24000) <= 120 and s.out_len == y.numel()
     assert abs(s.first_trim_end - (n - 36000)) <= 240
     rms_db = 20 * np.log10(float(torch.sqrt(torch.mean(y.double() ** 2))))
     assert abs(rms_db + 23.0) < 0.1                        # -23 dBFS target (tanh shaves a little)
