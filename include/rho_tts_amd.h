@@ -146,6 +146,122 @@ RT_API int rt_post_process_host(rt_ctx* ctx, const rt_post_params* p, int32_t n_
 /* float32 [-1,1] -> int16 PCM with the reference's truncating conversion (base_tts.py:664-666). */
 RT_API int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out);
 
+/* ------------------------------------------------------------------ model
+ * Stands behind the third-party model object the reference drives
+ * (providers/qwen.py:160-165 from_pretrained, :247-251 generate_custom_voice,
+ * :253-258 generate_voice_clone): talker decode + residual-code predictor +
+ * codec decoder, shape-parametrised (the real dimensions are UNVERIFIED offline).
+ */
+typedef struct rt_stack_dims {
+    int32_t hidden, layers, heads, kv_heads, head_dim, inter;
+    float rope_theta, rms_eps;
+} rt_stack_dims;
+
+typedef struct rt_model_config {
+    rt_stack_dims talker, predictor, codec_tf;
+    int32_t codec_vocab, predictor_vocab, text_vocab, text_hidden, n_groups;
+    int32_t codebook_size, num_quantizers, codec_sliding_window;
+    int32_t n_upsampling;         /* ConvNeXt upsample stages            */
+    int32_t upsampling_ratios[4];
+    int32_t n_upsample_rates;     /* decoder blocks                      */
+    int32_t upsample_rates[8];
+    int32_t decoder_dim;
+    int32_t codec_eos_id;
+    int32_t max_batch;            /* sequences decoded together          */
+    int32_t max_positions;        /* KV rows per sequence (prompt + frames) */
+    int32_t max_codec_frames;     /* frames per sequence one rt_code2wav call may decode */
+    int32_t reserved[4];
+} rt_model_config;
+
+#define RT_DTYPE_BF16 0
+#define RT_DTYPE_F32  1
+
+typedef struct rt_sampling {
+    int32_t do_sample;            /* 0: greedy (lowest index on ties)    */
+    float   temperature;
+    int32_t top_k;                /* 1..64 when sampling                 */
+    float   top_p;
+    float   repetition_penalty;   /* talker group 0 only                 */
+} rt_sampling;
+
+RT_API int rt_model_create(rt_ctx* ctx, const rt_model_config* cfg, rt_model** out_model);
+RT_API int rt_model_destroy(rt_model* m);
+/* Number of named tensors the model expects, and the name / shape of the i-th (INTEGRATION.md lists them). */
+RT_API int rt_model_tensor_count(rt_model* m);
+RT_API int rt_model_tensor_info(rt_model* m, int32_t index, char* name, size_t name_cap, int64_t* shape2, int32_t* kind);
+/* Upload one tensor (matrices [N][K] row-major bf16; vectors bf16 or f32).  on_device != 0: data is an HBM pointer. */
+RT_API int rt_model_set_tensor(rt_model* m, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols,
+                               int32_t on_device);
+/* After the last tensor: verifies completeness, uploads RoPE tables (h_* are [max_positions][head_dim/2] float32,
+ * one pair per stack: talker, predictor, codec_tf) and derives the projected predictor embedding tables. */
+RT_API int rt_model_finalize(rt_model* m, const float* h_rope_cos[3], const float* h_rope_sin[3]);
+RT_API int64_t rt_model_weight_bytes(rt_model* m);
+
+/* Voice conditioning = the shared prompt prefix, computed ONCE per voice (the reference re-derives it on every
+ * call by passing ref_audio=path each time, qwen.py:253-258).  Row recipe of the prefix, one entry per row:
+ *   h_text_ids[r]   text token of the row, or -1 for tts_pad
+ *   h_codec_ids[r*n_groups + g]  codec-side ids summed into the row (g = 0: talker table / control ids;
+ *                   g >= 1: residual codebook g), -1 = none
+ *   h_speaker_row   row that additionally receives h_speaker_embed[hidden] (float32), or -1
+ */
+RT_API int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids,
+                              int32_t h_speaker_row, const float* h_speaker_embed);
+RT_API int32_t rt_voice_prefix_len(rt_model* m);
+/* Prefix KV as one HBM blob [2][layers][kv_heads][prefix_len][head_dim] bf16, for an RCCL broadcast. */
+RT_API int64_t rt_voice_blob_bytes(rt_model* m);
+RT_API int rt_voice_export(rt_model* m, void* d_blob, int64_t bytes);
+RT_API int rt_voice_import(rt_model* m, int32_t prefix_len, const void* d_blob, int64_t bytes);
+
+typedef struct rt_generate_args {
+    int32_t n_items;
+    const int32_t* h_text_ids;      /* concatenated target-text token ids                          */
+    const int32_t* h_text_offsets;  /* [n_items + 1]                                               */
+    const int32_t* h_max_frames;    /* [n_items]                                                   */
+    const int64_t* h_item_ids;      /* [n_items] RNG stream of each item (its global index)        */
+    uint64_t seed;                  /* BaseTTS.seed (base_tts.py:45,142-149)                       */
+    rt_sampling talker, predictor;
+    int32_t ignore_eos;             /* synthetic weights never emit EOS: length = max_frames       */
+    int32_t min_frames;
+    int32_t tts_eos_id, tts_pad_id, codec_pad_id, codec_bos_id;
+    const int32_t* h_forced_codes;  /* optional teacher forcing: item i frames at offset forced_offsets[i], [frames][n_groups] */
+    const int32_t* h_forced_offsets;/* [n_items + 1], in frames                                    */
+    const volatile int32_t* h_cancel_flag; /* polled between frames (CancellationToken, cancellation.py:19-65) */
+    int32_t* h_codes;               /* out: item i at (sum_{j<i} max_frames[j]) * n_groups, [frames][n_groups] */
+    int32_t* h_n_frames;            /* out: [n_items]                                              */
+    float* d_trace_talker;          /* optional: [max_frames_max][n_items][codec_vocab] talker logits */
+    float* d_trace_predictor;       /* optional: [max_frames_max][n_groups-1][n_items][predictor_vocab] */
+} rt_generate_args;
+
+RT_API int rt_generate(rt_model* m, const rt_generate_args* args);
+
+/* Codec decoder: h_codes [n_items][t_max][num_quantizers] (right-padded), h_n_frames [n_items];
+ * d_wav [n_items][wav_stride] float32 in HBM, h_wav_len out.  rt_wav_length(frames) = samples produced. */
+RT_API int64_t rt_wav_length(rt_model* m, int32_t n_frames);
+RT_API int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_codes, const int32_t* h_n_frames,
+                       float* d_wav, int64_t wav_stride, int64_t* h_wav_len);
+
+/* Per-kernel timing of the decode step for bench.py's roofline figure: when enabled, every weight-streaming GEMM
+ * launch is bracketed by HIP events on the context's stream. */
+RT_API int rt_profile_enable(rt_model* m, int32_t on);
+RT_API int rt_profile_read(rt_model* m, int64_t* n_launches, double* total_ms, double* total_bytes);
+
+/* ------------------------------------------------------------------ kernel-level test hooks
+ * Exercise single kernels against a float32 reference (tests/test_kernels_gpu.py).  All pointers are HBM.
+ * rt_debug_gemm: out[M][N] (f32) = A . W^T for a row-major bf16 W[N][K=taps*cin]; A is the implicit-GEMM view
+ * of a channels-last activation [batch][rows_in][cin] (bf16, or f32 when a_is_f32): output row (b, t) reads input
+ * rows t + tap_offset + tap*tap_stride, zero outside [0, rows_in).  mode 0: LDS-tiled kernel (split_k slabs are
+ * summed on return), mode 1: weight-streaming skinny kernel (plain A only, M <= 64). */
+RT_API int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int32_t cin, int32_t taps, int32_t tap_stride,
+                         int32_t tap_offset, int32_t rows_out, int32_t rows_in, const void* d_w_bf16, int32_t N,
+                         const float* d_bias, int32_t act, float* d_out, int32_t mode, int32_t split_k);
+/* q [M][heads][d] f32, caches [slots][kv_heads][max_pos][d] bf16 -> out [M][heads*d] bf16 */
+RT_API int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                              const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t window, const void* d_k, const void* d_v,
+                              int32_t slots, int32_t max_pos, void* d_out_bf16);
+/* One draw per row: logits [M][V] f32 -> tokens [M].  item ids 0..M-1. */
+RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed,
+                           int32_t frame, int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,156 @@
+// KV-cached attention for gfx950: one workgroup per (row, kv-head), K/V streamed straight to VGPRs
+// (each K/V byte is used once: no LDS round trip), 16-B loads, D/8 lanes per cached position,
+// wave-shuffle dot-product reduction, per-lane-group online softmax merged at the end.
+// Serves the decode step (one row per sequence), the prompt prefill (row t sees rows <= t of its
+// slot) and the codec pre-transformer (sliding window).  HBM-bound: 2 * ctx * head_dim * 2 bytes
+// per (row, kv-head).
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+
+template <int D, int REP>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, int heads, int kv_heads,
+                                                   const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
+                                                   int pos_add, int window, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                   int max_pos, bf16_t* __restrict__ out) {
+    constexpr int LPP = D / 8;        // lanes per cached position
+    constexpr int PPW = 64 / LPP;     // positions per wave step
+    constexpr int U = 4;              // positions in flight per lane
+    __shared__ float sh[4][REP][LPP][10];
+
+    const int row = blockIdx.x, kh = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sub = lane % LPP, pg = lane / LPP;
+    const int hi = row_pos[row] + pos_add;
+    int lo = 0;
+    if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
+    const int slot = row_slot[row];
+    const float scale = rsqrtf((float)D);
+
+    float qr[REP][8];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        const float* qp = q + ((int64_t)row * heads + kh * REP + r) * D + sub * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qr[r][j] = qp[j] * scale;
+    }
+    float m[REP], l[REP], acc[REP][8];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+        m[r] = -1e30f;
+        l[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
+    }
+    const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
+    const bf16_t* kb = kc + base * D + sub * 8;
+    const bf16_t* vb = vc + base * D + sub * 8;
+
+    for (int p0 = lo + w * PPW + pg; p0 <= hi; p0 += 4 * PPW * U) {
+        u4_t kk[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * 4 * PPW;
+            const int pc = p <= hi ? p : hi;
+            kk[u] = *reinterpret_cast<const u4_t*>(kb + (int64_t)pc * D);
+            vv[u] = *reinterpret_cast<const u4_t*>(vb + (int64_t)pc * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * 4 * PPW;
+            float kf[8], vf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = __uint_as_float(kk[u][j] << 16);
+                kf[2 * j + 1] = __uint_as_float(kk[u][j] & 0xffff0000u);
+                vf[2 * j] = __uint_as_float(vv[u][j] << 16);
+                vf[2 * j + 1] = __uint_as_float(vv[u][j] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int r = 0; r < REP; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += qr[r][j] * kf[j];
+#pragma unroll
+                for (int o = 1; o < LPP; o <<= 1) s += __shfl_xor(s, o, 64);
+                if (p <= hi) {   // uniform within the LPP-lane group
+                    const float mn = fmaxf(m[r], s);
+                    const float corr = __expf(m[r] - mn), pe = __expf(s - mn);
+                    l[r] = l[r] * corr + pe;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[r][j] = acc[r][j] * corr + pe * vf[j];
+                    m[r] = mn;
+                }
+            }
+        }
+    }
+    // merge the PPW position groups of the wave (lanes sharing `sub`)
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int o = LPP; o < 64; o <<= 1) {
+            const float m2 = __shfl_xor(m[r], o, 64), l2 = __shfl_xor(l[r], o, 64);
+            const float mn = fmaxf(m[r], m2);
+            const float c1 = __expf(m[r] - mn), c2 = __expf(m2 - mn);
+            l[r] = l[r] * c1 + l2 * c2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r][j] = acc[r][j] * c1 + __shfl_xor(acc[r][j], o, 64) * c2;
+            m[r] = mn;
+        }
+        if (pg == 0) {
+            sh[w][r][sub][0] = m[r];
+            sh[w][r][sub][1] = l[r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sh[w][r][sub][2 + j] = acc[r][j];
+        }
+    }
+    __syncthreads();
+    // final merge over the 4 waves: thread t -> (r, sub, j)
+    for (int t = threadIdx.x; t < REP * LPP * 8; t += 256) {
+        const int j = t & 7, sb = (t >> 3) % LPP, r = t / (8 * LPP);
+        float mn = -1e30f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) mn = fmaxf(mn, sh[ww][r][sb][0]);
+        float lt = 0.f, at = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float c = __expf(sh[ww][r][sb][0] - mn);
+            lt += sh[ww][r][sb][1] * c;
+            at += sh[ww][r][sb][2 + j] * c;
+        }
+        out[((int64_t)row * heads + kh * REP + r) * D + sb * 8 + j] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
+    }
+}
+
+template <int D>
+int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
+                 int pos_add, int window, const bf16_t* kc, const bf16_t* vc, int max_pos, bf16_t* out) {
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((k_attention<D, 1>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
+        default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
+    }
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out) {
+    if (M <= 0) return RT_OK;
+    if (heads % kv_heads) return rt_fail(ctx, RT_ERR_INVALID, "attention: heads %d not a multiple of kv_heads %d", heads, kv_heads);
+    const int rep = heads / kv_heads;
+    const bf16_t* kc = kv.k + layer * kv.layer_stride();
+    const bf16_t* vc = kv.v + layer * kv.layer_stride();
+    dim3 grid(M, kv_heads);
+    switch (head_dim) {
+        case 32: return dispatch_rep<32>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
+        case 64: return dispatch_rep<64>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
+        case 128: return dispatch_rep<128>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
+        default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32, 64, 128)", head_dim);
+    }
+}

@@ -1,0 +1,89 @@
+// Kernel-level test hooks of the C ABI (include/rho_tts_amd.h, "kernel-level test hooks").
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+__global__ void k_iota64(int64_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int32_t cin, int32_t taps, int32_t tap_stride,
+                  int32_t tap_offset, int32_t rows_out, int32_t rows_in, const void* d_w_bf16, int32_t N, const float* d_bias,
+                  int32_t act, float* d_out, int32_t mode, int32_t split_k) {
+    if (!ctx || !d_a || !d_w_bf16 || !d_out || M < 1 || N < 1 || cin < 8 || taps < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int K = cin * taps;
+    bf16_t* packed = nullptr;
+    float* slabs = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&packed, packed_bytes(N, K)));
+    PackedW pw;
+    int rc = launch_pack_weight(ctx, (const bf16_t*)d_w_bf16, N, K, packed, &pw);
+    if (!rc) {
+        if (mode == 1) {
+            if (a_is_f32 || taps != 1) rc = rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm: skinny mode needs a plain bf16 A");
+            else {
+                if (split_k < 1) split_k = skinny_pick_split((int)M, N, K, ctx->n_cu);
+                if (hipMalloc((void**)&slabs, (size_t)split_k * M * N * 4) != hipSuccess) rc = RT_ERR_OOM;
+                if (!rc) rc = launch_gemm_skinny(ctx, (const bf16_t*)d_a, (int)M, pw, slabs, N, split_k);
+                if (!rc) rc = launch_reduce_slabs(ctx, slabs, split_k, M, N, d_bias, act, d_out, nullptr);
+            }
+        } else {
+            GemmA a; a.ptr = d_a; a.is_f32 = a_is_f32; a.M = M; a.Cin = cin; a.taps = taps; a.tap_stride = tap_stride; a.tap_offset = tap_offset;
+            a.rows_out = rows_out; a.rows_in = rows_in;
+            GemmEpi e; e.ldc = N;
+            if (split_k <= 1) {
+                e.bias = d_bias; e.act = act; e.out_f32 = d_out; e.split_k = 1;
+                rc = launch_gemm(ctx, a, pw, e);
+            } else {
+                if (hipMalloc((void**)&slabs, (size_t)split_k * M * N * 4) != hipSuccess) rc = RT_ERR_OOM;
+                e.out_f32 = slabs; e.split_k = split_k;
+                if (!rc) rc = launch_gemm(ctx, a, pw, e);
+                if (!rc) rc = launch_reduce_slabs(ctx, slabs, split_k, M, N, d_bias, act, d_out, nullptr);
+            }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    if (packed) (void)hipFree(packed);
+    if (slabs) (void)hipFree(slabs);
+    return rc;
+}
+
+int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim, const int32_t* d_row_slot,
+                       const int32_t* d_row_pos, int32_t window, const void* d_k, const void* d_v, int32_t slots, int32_t max_pos,
+                       void* d_out_bf16) {
+    if (!ctx || !d_q || !d_k || !d_v || !d_out_bf16) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention: null argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    KvCache kv;
+    kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
+    int rc = launch_attention(ctx, d_q, M, heads, kv_heads, head_dim, d_row_slot, d_row_pos, 0, window, kv, 0, (bf16_t*)d_out_bf16);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed, int32_t frame,
+                    int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out) {
+    if (!ctx || !d_logits || !sp || !d_out || M < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_sample: null argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t* items = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&items, (size_t)M * 8));
+    hipLaunchKernelGGL(k_iota64, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, items, M);
+    SampleArgs a{};
+    a.logits = d_logits; a.n_slabs = 1; a.M = M; a.V = V;
+    a.do_sample = sp->do_sample; a.temperature = sp->temperature; a.top_k = sp->top_k; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
+    a.seen = d_seen; a.suppress_from = suppress_from; a.allow_token = allow_token; a.seed = seed; a.item_ids = items; a.frame = frame; a.group = group;
+    a.forced = nullptr; a.out = d_out; a.out_stride = 1; a.eos_token = -1; a.eos_flag = nullptr; a.logits_copy = nullptr;
+    int rc = launch_sample(ctx, a);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(items);
+    return rc;
+}
+
+}  // extern "C"

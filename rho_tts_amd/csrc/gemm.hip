@@ -1,0 +1,352 @@
+// bf16 MFMA GEMMs for gfx950 (v_mfma_f32_32x32x16_bf16, 64-lane waves).
+//
+//   k_pack_weight   W[N][K] row-major -> B-fragment tile order (one coalesced 1-KiB load per operand)
+//   k_gemm_skinny   decode form, M <= 64 rows: every weight byte streamed from HBM exactly once
+//                   (non-temporal), activations from L2, split-K partial slabs (deterministic sum
+//                   in the consumer instead of float atomics).  HBM-bound: N*K*2 bytes per launch.
+//   k_gemm_tiled    128x128x32 LDS-staged implicit GEMM for prefill and the codec decoder's
+//                   conv-as-GEMM contractions (causal dilated conv1d, transposed conv1d), fused
+//                   bias / activation / layer-scale / residual / SnakeBeta epilogue.  MFMA-bound.
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+typedef __attribute__((ext_vector_type(16))) float f16_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+typedef __attribute__((ext_vector_type(4))) int i4_t;
+
+__device__ __forceinline__ f16_t mfma32(s8_t a, s8_t b, f16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+
+// ------------------------------------------------------------------------------------------ pack
+__global__ void k_pack_weight(const bf16_t* __restrict__ src, int N, int K, int Np, int Kp, bf16_t* __restrict__ dst) {
+    const int KT = Kp / 16;
+    const int64_t n_pieces = (int64_t)(Np / 32) * KT * 64;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pieces; p += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(p & 63);
+        const int64_t tile = p >> 6;
+        const int kt = (int)(tile % KT);
+        const int nt = (int)(tile / KT);
+        const int n = nt * 32 + (lane & 31);
+        const int k0 = kt * 16 + (lane >> 5) * 8;
+        bf16_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? src[(int64_t)n * K + k0 + j] : (bf16_t)0;
+        *reinterpret_cast<s8_t*>(dst + p * 8) = *reinterpret_cast<s8_t*>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- skinny
+// grid.x = Np/32 n-tiles (one wave each, 4 waves per workgroup), grid.y = split_k.
+template <int MT>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t* __restrict__ A, int M, int K, const bf16_t* __restrict__ Wp,
+                                                     int NT, int KT, int kt_per_split, float* __restrict__ out, int64_t ldc,
+                                                     int N) {
+    const int lane = threadIdx.x & 63;
+    const int nt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (nt >= NT) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int kt0 = blockIdx.y * kt_per_split;
+    int kt1 = kt0 + kt_per_split;
+    if (kt1 > KT) kt1 = KT;
+    const s8_t* wp = reinterpret_cast<const s8_t*>(Wp) + ((int64_t)nt * KT + kt0) * 64 + lane;
+    const bf16_t* ap[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int row = mt * 32 + r;
+        if (row >= M) row = M - 1;  // clamp: rows >= M are computed on valid memory and never stored
+        ap[mt] = A + (int64_t)row * K + h * 8;
+    }
+    f16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    const int n_k = kt1 - kt0;
+    int kt = 0;
+    constexpr int U = 8;
+    for (; kt + U <= n_k; kt += U) {
+        s8_t b[U];
+        s8_t a[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = __builtin_nontemporal_load(wp + (int64_t)(kt + u) * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = *reinterpret_cast<const s8_t*>(ap[mt] + (int64_t)(kt0 + kt + u) * 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(a[u][mt], b[u], acc[mt]);
+    }
+    for (; kt < n_k; ++kt) {
+        const s8_t b = __builtin_nontemporal_load(wp + (int64_t)kt * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const s8_t a = *reinterpret_cast<const s8_t*>(ap[mt] + (int64_t)(kt0 + kt) * 16);
+            acc[mt] = mfma32(a, b, acc[mt]);
+        }
+    }
+    float* o = out + (int64_t)blockIdx.y * M * ldc;
+    const int n = nt * 32 + r;
+    if (n < N) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < M) o[(int64_t)row * ldc + n] = acc[mt][i];
+            }
+    }
+}
+
+// ----------------------------------------------------------------------------------------- tiled
+constexpr int BM = 128, BN = 128, BK = 32;
+
+struct TiledArgs {
+    GemmA a;
+    const bf16_t* Wp;
+    int N, K, NT, KT;
+    GemmEpi e;
+    int kt_per_split;  // in 16-wide k tiles, multiple of 2
+};
+
+__device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B rows, 16-B slots XOR-swizzled by row/4
+    return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+}
+
+template <bool A_F32>
+__global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;   // x: row tiles (can exceed 65535), y: column tiles
+    const int n0 = blockIdx.y * BN;
+    const int kt0 = blockIdx.z * g.kt_per_split;
+    int kt1 = kt0 + g.kt_per_split;
+    if (kt1 > g.KT) kt1 = g.KT;
+    const int n_it = (kt1 - kt0 + 1) / 2;
+
+    // ---- per-thread A staging state: pieces p = tid, tid+256 -> (row = p>>2, slot = p&3)
+    int64_t row_base[2];   // element offset of (b, t=0... ) i.e. b*rows_in*Cin
+    int row_t[2];          // t + tap_offset
+    bool row_ok[2];
+    int p_tap[2], p_ci[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = tid + i * 256;
+        const int row = p >> 2, slot = p & 3;
+        const int64_t m = m0 + row;
+        row_ok[i] = m < g.a.M;
+        int64_t b = 0, t = m;
+        if (g.a.rows_out > 0) { b = m / g.a.rows_out; t = m - b * g.a.rows_out; }
+        const int rows_in = g.a.rows_out > 0 ? g.a.rows_in : 0;
+        row_base[i] = b * (int64_t)rows_in * g.a.Cin;
+        row_t[i] = (int)t + g.a.tap_offset;
+        const int kk = kt0 * 16 + slot * 8;
+        p_tap[i] = kk / g.a.Cin;
+        p_ci[i] = kk - p_tap[i] * g.a.Cin;
+    }
+    const int t_limit = g.a.rows_out > 0 ? g.a.rows_in : 0x7fffffff;
+
+    auto load_piece = [&](int i, s8_t& dst) {
+        const int ti = row_t[i] + p_tap[i] * g.a.tap_stride;
+        const bool ok = row_ok[i] && p_tap[i] < g.a.taps && ti >= 0 && (g.a.rows_out == 0 || ti < t_limit);
+        if (ok) {
+            const int64_t off = row_base[i] + (int64_t)ti * g.a.Cin + p_ci[i];
+            if (A_F32) {
+                const float* s = reinterpret_cast<const float*>(g.a.ptr) + off;
+                const f4_t v0 = *reinterpret_cast<const f4_t*>(s), v1 = *reinterpret_cast<const f4_t*>(s + 4);
+                i4_t pk;
+                pk[0] = (int)pack_bf16x2(v0[0], v0[1]);
+                pk[1] = (int)pack_bf16x2(v0[2], v0[3]);
+                pk[2] = (int)pack_bf16x2(v1[0], v1[1]);
+                pk[3] = (int)pack_bf16x2(v1[2], v1[3]);
+                dst = __builtin_bit_cast(s8_t, pk);
+            } else {
+                dst = *reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.a.ptr) + off);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = 0;
+        }
+        // advance this piece by BK along K for the next iteration
+        p_ci[i] += BK;
+        while (p_ci[i] >= g.a.Cin) { p_ci[i] -= g.a.Cin; ++p_tap[i]; }
+    };
+    auto store_piece = [&](int i, int buf, const s8_t& v) {
+        const int p = tid + i * 256;
+        *reinterpret_cast<s8_t*>(lds + buf * (BM * 64) + lds_a_off(p >> 2, p & 3)) = v;
+    };
+    // ---- B fragments straight from the packed weights (global -> VGPR), one 16-B load per (nt, kt)
+    const int nt_base = (n0 >> 5) + wn * 2;
+    auto load_b = [&](int it, s8_t (&b)[2][2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int t_n = nt_base + nt, t_k = kt0 + it * 2 + kk;
+                if (t_n < g.NT && t_k < kt1)
+                    b[nt][kk] = *(reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)t_n * g.KT + t_k) * 64 + lane);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[nt][kk][j] = 0;
+                }
+            }
+    };
+
+    f16_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    s8_t ra[2], rb[2][2], rb_next[2][2];
+    load_piece(0, ra[0]);
+    load_piece(1, ra[1]);
+    load_b(0, rb);
+    store_piece(0, 0, ra[0]);
+    store_piece(1, 0, ra[1]);
+    __syncthreads();
+
+    for (int it = 0; it < n_it; ++it) {
+        const int buf = it & 1;
+        const bool more = it + 1 < n_it;
+        if (more) {
+            load_piece(0, ra[0]);
+            load_piece(1, ra[1]);
+            load_b(it + 1, rb_next);
+        }
+        s8_t fa[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * (BM * 64) + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(fa[mt][kk], rb[nt][kk], acc[mt][nt]);
+        if (more) {
+            store_piece(0, buf ^ 1, ra[0]);
+            store_piece(1, buf ^ 1, ra[1]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) rb[nt][kk] = rb_next[nt][kk];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const GemmEpi& e = g.e;
+    const int64_t M = g.a.M;
+    float* slab = e.out_f32 ? e.out_f32 + (int64_t)blockIdx.z * M * e.ldc : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wn * 64 + nt * 32 + r;
+            if (n >= g.N) continue;
+            float bias = 0.f, scale = 1.f, sa = 0.f, sib = 0.f, s2a = 0.f, s2ib = 0.f;
+            if (e.split_k == 1) {
+                if (e.bias) bias = e.bias[n];
+                if (e.scale) scale = e.scale[n];
+                if (e.act == ACT_SNAKE) { sa = e.snake_a[n]; sib = e.snake_ib[n]; }
+                if (e.out2_bf16) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m >= M) continue;
+                float v = acc[mt][nt][i];
+                const int64_t o = m * e.ldc + n;
+                if (e.split_k > 1) { slab[o] = v; continue; }
+                v += bias;
+                if (e.act == ACT_SILU) v = v / (1.f + __expf(-v));
+                else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                else if (e.act == ACT_SNAKE) { const float s = __sinf(v * sa); v = v + sib * s * s; }
+                v *= scale;
+                if (e.residual) v += e.residual[o];
+                if (e.out_f32) e.out_f32[o] = v;
+                if (e.out_bf16) e.out_bf16[o] = f32_to_bf16(v);
+                if (e.out2_bf16) { const float s = __sinf(v * s2a); e.out2_bf16[o] = f32_to_bf16(v + s2ib * s * s); }
+            }
+        }
+}
+
+}  // namespace
+
+size_t packed_bytes(int N, int K) {
+    const size_t Np = (size_t)(N + 31) / 32 * 32, Kp = (size_t)(K + 15) / 16 * 16;
+    return Np * Kp * 2;
+}
+
+int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out) {
+    const int Np = (N + 31) / 32 * 32, Kp = (K + 15) / 16 * 16;
+    const int64_t pieces = (int64_t)(Np / 32) * (Kp / 16) * 64;
+    int64_t blocks = (pieces + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_src, N, K, Np, Kp, d_dst);
+    RT_HIP(ctx, hipGetLastError());
+    out->data = d_dst;
+    out->N = N; out->K = K; out->Np = Np; out->Kp = Kp;
+    return RT_OK;
+}
+
+int skinny_pick_split(int M, int N, int K, int n_cu) {
+    const int tiles = (N + 31) / 32, KT = (K + 15) / 16;
+    const int target = n_cu * 4;  // one wave per SIMD
+    int s = 1;
+    while (s < 16 && tiles * (s * 2) <= target && KT % (s * 2) == 0 && KT / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
+int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k) {
+    if (M < 1 || M > 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: M=%d outside 1..64", M);
+    if (w.K != w.Kp) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: K=%d must be a multiple of 16", w.K);
+    const int NT = w.Np / 32, KT = w.Kp / 16;
+    if (split_k < 1 || KT % split_k) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: split_k=%d does not divide %d k-tiles", split_k, KT);
+    dim3 grid((NT + 3) / 4, split_k);
+    if (M <= 32)
+        hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+    else
+        hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e) {
+    if (a.M <= 0) return RT_OK;
+    if (a.Cin % 8 || (int64_t)a.Cin * a.taps != w.K)
+        return rt_fail(ctx, RT_ERR_INVALID, "gemm: A has taps=%d Cin=%d but W has K=%d", a.taps, a.Cin, w.K);
+    if (e.split_k < 1 || (e.split_k > 1 && !e.out_f32)) return rt_fail(ctx, RT_ERR_INVALID, "gemm: bad split_k");
+    TiledArgs g;
+    g.a = a;
+    g.Wp = w.data;
+    g.N = w.N; g.K = w.K; g.NT = w.Np / 32; g.KT = w.Kp / 16;
+    g.e = e;
+    int per = (g.KT + e.split_k - 1) / e.split_k;
+    per = (per + 1) / 2 * 2;
+    g.kt_per_split = per;
+    const int64_t my = (a.M + BM - 1) / BM;
+    if (my > 0x7fffffff) return rt_fail(ctx, RT_ERR_LENGTH, "gemm: length %lld rows too large", (long long)a.M);
+    dim3 grid((unsigned)my, (w.N + BN - 1) / BN, e.split_k);
+    if (a.is_f32) hipLaunchKernelGGL(k_gemm_tiled<true>, grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL(k_gemm_tiled<false>, grid, dim3(256), 0, ctx->stream, g);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}

@@ -1,0 +1,130 @@
+// Launch-level interface of the gfx950 kernels (internal; the public C ABI is include/rho_tts_amd.h).
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ GEMM
+// Weights are bf16 matrices W[N][K] (torch Linear layout) re-tiled once at load time into
+// MFMA B-fragment order for v_mfma_f32_32x32x16_bf16: tile (nt, kt) covers rows nt*32..+32 and
+// k kt*16..+16 and is stored as 64 lanes x 16 B, lane (h<<5 | r) holding W[nt*32+r][kt*16+8h .. +8].
+// A wave's B operand is then ONE fully coalesced 1-KiB load, and all K of a 32-row block is contiguous.
+struct PackedW {
+    const bf16_t* data = nullptr;  // [Np/32][Kp/16][64][8]
+    int N = 0, K = 0;              // logical
+    int Np = 0, Kp = 0;            // padded to 32 / 16 (zero filled)
+    size_t bytes() const { return (size_t)Np * Kp * 2; }
+};
+
+// Implicit-GEMM view of the A operand: row m = (b, t) of an activation tensor [B][T_in][Cin]
+// (channels-last); column kk = tap*Cin + ci reads A[b][t + tap_offset + tap*tap_stride][ci],
+// zero outside [0, T_in).  A plain matrix is taps = 1, rows_out = rows_in = M.
+struct GemmA {
+    const void* ptr = nullptr;
+    int is_f32 = 0;        // 1: float32 source converted to bf16 on load; 0: bf16
+    int64_t M = 0;
+    int Cin = 0;           // K = taps * Cin, Cin % 8 == 0
+    int taps = 1;
+    int tap_stride = 1;
+    int tap_offset = 0;
+    int rows_out = 0;      // output rows per batch item (0: not batched)
+    int rows_in = 0;       // input rows per batch item
+};
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SNAKE = 3 };
+
+// out = (act(acc + bias)) * scale + residual, optionally also out2 = snake2(out) in bf16.
+// All per-column vectors have length N.  With split_k > 1 only raw f32 partial slabs are written
+// (slab s at out_f32 + s*M*ldc) and the consumer sums them.
+struct GemmEpi {
+    const float* bias = nullptr;
+    const float* scale = nullptr;
+    const float* residual = nullptr;
+    float* out_f32 = nullptr;
+    bf16_t* out_bf16 = nullptr;
+    int act = ACT_NONE;
+    const float* snake_a = nullptr;      // exp(alpha)
+    const float* snake_ib = nullptr;     // 1 / (exp(beta) + 1e-9)
+    bf16_t* out2_bf16 = nullptr;
+    const float* snake2_a = nullptr;
+    const float* snake2_ib = nullptr;
+    int64_t ldc = 0;
+    int split_k = 1;
+};
+
+size_t packed_bytes(int N, int K);
+// d_dst must hold packed_bytes(N, K); d_src is row-major bf16 [N][K] in HBM.
+int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
+int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e);
+// Weight-streaming form for M <= 64 rows (decode): plain bf16 A [M][K], raw f32 slabs out.
+int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k);
+int skinny_pick_split(int M, int N, int K, int n_cu);
+
+// ---------------------------------------------------------------------------------- row kernels
+// x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
+//   x += scale[:] * sum_s slab[s]   (slab stride M*H; scale may be null)
+//   xn = rmsnorm(x) * w  -> bf16 and/or f32
+int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, int n_slabs, const float* slab_bias,
+                       const float* scale, const float* w, float eps, bf16_t* out_bf16, float* out_f32);
+// act[M][I] = silu(g) * u with g = sum_s slab[s][m][0:I], u = sum_s slab[s][m][I:2I]  -> bf16
+int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out);
+// y[M][N] = sum_s slab[s] (+ bias), optionally activation, to f32 and/or bf16
+int launch_reduce_slabs(rt_ctx* ctx, const float* slabs, int n_slabs, int64_t M, int N, const float* bias, int act,
+                        float* out_f32, bf16_t* out_bf16);
+
+struct KvCache {
+    bf16_t* k = nullptr;   // [layers][slots][kv_heads][max_pos][head_dim]
+    bf16_t* v = nullptr;
+    int layers = 0, slots = 0, kv_heads = 0, max_pos = 0, head_dim = 0;
+    size_t layer_stride() const { return (size_t)slots * kv_heads * max_pos * head_dim; }
+};
+// qkv slabs [S][M][(heads+2*kv_heads)*d] -> q (f32 [M][heads][d], normed + roped), k/v appended to the cache
+int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int heads, int kv_heads, int head_dim,
+                    const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin,
+                    const int32_t* row_slot, const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer);
+// o[M][heads*d] (bf16) = softmax(q k^T / sqrt(d)) v over cache rows [max(0,pos-window+1), pos] of the row's slot
+int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out);
+
+// ------------------------------------------------------------------------------ embedding kernels
+// out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.
+struct GatherSrc {
+    const bf16_t* table;
+    int64_t row_stride;  // elements
+};
+int launch_gather_sum(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const int32_t* d_idx, int M, int H,
+                      const float* add_vec, const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16);
+int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16);
+
+// ------------------------------------------------------------------------------------- sampling
+struct SampleArgs {
+    const float* logits;       // [M][V] (sum of n_slabs slabs, slab stride M*V)
+    int n_slabs;
+    int M, V;
+    int do_sample;
+    float temperature;
+    int top_k;
+    float top_p;
+    float rep_penalty;
+    uint8_t* seen;             // [M][V] or null (repetition history, updated with the drawn token)
+    int suppress_from;         // tokens >= suppress_from are forbidden ...
+    int allow_token;           // ... except this one (-1: none)
+    uint64_t seed;
+    const int64_t* item_ids;   // [M]
+    int frame, group;
+    const int32_t* forced;     // [M] or null: teacher forcing (value < 0 = not forced)
+    int32_t* out;              // token of row r goes to out[r * out_stride]
+    int out_stride;
+    int eos_token;             // >= 0: a drawn eos is reported in eos_flag[r] and replaced by 0 in `out`
+    int32_t* eos_flag;         // [M] or null
+    float* logits_copy;        // optional [M][V] summed logits for tracing
+};
+int launch_sample(rt_ctx* ctx, const SampleArgs& a);
+
+// -------------------------------------------------------------------------------- codec elementwise
+int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* a, const float* ib, bf16_t* out_bf16);
+int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w /*[7][C]*/, const float* b,
+                     const float* ln_w, const float* ln_b, float eps, bf16_t* out_bf16);
+int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q, int H, const int32_t* codes /*[B][T][Q]*/,
+                           int64_t rows, float* out_f32);
+int launch_final_conv(rt_ctx* ctx, const bf16_t* x_snaked, int B, int T, int C, const float* w /*[7][C]*/, float bias,
+                      float* wav /*[B][T]*/);
+int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out);

@@ -1,0 +1,1024 @@
+// Model group of the C ABI: weights, voice prefix, autoregressive decode, codec decoder.
+// Host-side orchestration only — every FLOP and byte moves in the kernels of gemm.hip, rowops.hip,
+// attention.hip and sampling.hip.  Stands behind the third-party model object the reference drives at
+// providers/qwen.py:160-165 (load), :247-258 (generate_custom_voice / generate_voice_clone).
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "kernels.h"
+
+namespace {
+
+enum SlotKind { K_GEMM = 0, K_TABLE = 1, K_VEC = 2 };
+
+struct Slot {
+    std::string name;
+    int kind = 0;
+    int64_t rows = 0, cols = 0;
+    bool set = false;
+    PackedW pw;
+    bf16_t* tbl = nullptr;
+    float* vec = nullptr;
+    void* raw = nullptr;  // owning pointer
+};
+
+struct LayerW {
+    PackedW wqkv, wo, wgu, wd;
+    float *ln1 = nullptr, *ln2 = nullptr, *qn = nullptr, *kn = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+};
+
+struct StackW {
+    rt_stack_dims d{};
+    std::vector<LayerW> L;
+    float* norm = nullptr;
+    int window = 0;
+    KvCache kv;
+    float *cos = nullptr, *sin = nullptr;
+    int q_dim() const { return d.heads * d.head_dim; }
+    int kv_dim() const { return d.kv_heads * d.head_dim; }
+};
+
+struct PoolBlock { void* p; size_t size; bool used; };
+
+__global__ void k_bf16_to_f32(const bf16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = bf16_to_f32(x[i]);
+}
+// prefix KV (slot `src`) -> every slot in [0, n_dst): one workgroup per (layer*kv_head, dst slot)
+__global__ void k_kv_fanout(bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int64_t layer_stride, int kv_heads, int max_pos, int d,
+                            int src, int prefix_len) {
+    const int lh = blockIdx.x, dst = blockIdx.y;
+    const int layer = lh / kv_heads, kh = lh % kv_heads;
+    const int64_t so = layer * layer_stride + ((int64_t)src * kv_heads + kh) * max_pos * d;
+    const int64_t dof = layer * layer_stride + ((int64_t)dst * kv_heads + kh) * max_pos * d;
+    const int64_t n16 = (int64_t)prefix_len * d / 8;
+    const uint4* ks = reinterpret_cast<const uint4*>(kc + so);
+    const uint4* vs = reinterpret_cast<const uint4*>(vc + so);
+    uint4* kd = reinterpret_cast<uint4*>(kc + dof);
+    uint4* vd = reinterpret_cast<uint4*>(vc + dof);
+    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) { kd[i] = ks[i]; vd[i] = vs[i]; }
+}
+// blob [2][layers][kv_heads][prefix_len][d] <-> cache slot
+__global__ void k_kv_blob(bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int64_t layer_stride, int layers, int kv_heads, int max_pos,
+                          int d, int slot, int prefix_len, bf16_t* __restrict__ blob, int to_blob) {
+    const int lh = blockIdx.x, which = blockIdx.y;
+    const int layer = lh / kv_heads, kh = lh % kv_heads;
+    bf16_t* c = (which ? vc : kc) + layer * layer_stride + ((int64_t)slot * kv_heads + kh) * max_pos * d;
+    bf16_t* b = blob + (((int64_t)which * layers + layer) * kv_heads + kh) * prefix_len * d;
+    const int64_t n16 = (int64_t)prefix_len * d / 8;
+    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) {
+        if (to_blob) reinterpret_cast<uint4*>(b)[i] = reinterpret_cast<const uint4*>(c)[i];
+        else reinterpret_cast<uint4*>(c)[i] = reinterpret_cast<const uint4*>(b)[i];
+    }
+}
+__global__ void k_add_vec(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+__global__ void k_fill_i32(int32_t* p, int n, int v, int step_every, int step) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v + (step_every > 0 ? (i / step_every) * step : 0);
+}
+
+}  // namespace
+
+struct rt_model {
+    rt_ctx* ctx = nullptr;
+    rt_model_config cfg{};
+    std::vector<Slot> slots;
+    std::map<std::string, int> by_name;
+    bool finalized = false;
+    StackW talker, pred, ctf;
+    std::vector<int> dec_ch;  // decoder channel ladder
+    // derived tables
+    float* pad_t = nullptr;   // text_proj(tts_pad)  [H]  (computed on first use)
+    int pad_t_id = -1;
+    float* proj_c0 = nullptr;              // [codec_vocab][Hp] f32 (mtp only)
+    std::vector<float*> proj_emb;          // [G-1] x [Vp][Hp] f32 (mtp only)
+    GatherSrc* d_frame_srcs = nullptr;     // n_groups sources for frame embedding
+    std::vector<float*> exp_vecs;          // expanded per-column vectors (owned)
+    std::map<std::string, float*> xvec;    // name -> expanded vector (SnakeBeta parameters tiled over a transposed conv's r phases)
+    // voice
+    int prefix_len = 0;
+    // pool
+    std::vector<PoolBlock> pool;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t prof_used = 0;
+    double prof_bytes = 0;
+    int64_t weight_bytes = 0;
+
+    bool has_mtp() const { return cfg.talker.hidden != cfg.predictor.hidden; }
+    int prefix_slot() const { return cfg.max_batch; }
+};
+
+namespace {
+
+#define RT_TRY(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc) return _rc;    \
+    } while (0)
+
+int pool_get(rt_model* m, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (size_t i = 0; i < m->pool.size(); ++i)
+        if (!m->pool[i].used && m->pool[i].size >= bytes && (best < 0 || m->pool[i].size < m->pool[best].size)) best = (int)i;
+    if (best >= 0 && m->pool[best].size <= bytes * 2 + (1 << 20)) {
+        m->pool[best].used = true;
+        *out = m->pool[best].p;
+        return RT_OK;
+    }
+    void* p = nullptr;
+    const size_t sz = (bytes + 255) & ~(size_t)255;
+    RT_HIP(m->ctx, hipMalloc(&p, sz));
+    m->pool.push_back({p, sz, true});
+    *out = p;
+    return RT_OK;
+}
+void pool_release_all(rt_model* m) {
+    for (auto& b : m->pool) b.used = false;
+}
+template <typename T>
+int pool_arr(rt_model* m, size_t n, T** out) {
+    void* p = nullptr;
+    RT_TRY(pool_get(m, n * sizeof(T), &p));
+    *out = (T*)p;
+    return RT_OK;
+}
+
+void add_slot(rt_model* m, const std::string& name, int kind, int64_t rows, int64_t cols) {
+    Slot s;
+    s.name = name; s.kind = kind; s.rows = rows; s.cols = cols;
+    m->by_name[name] = (int)m->slots.size();
+    m->slots.push_back(s);
+}
+Slot* find_slot(rt_model* m, const std::string& name) {
+    auto it = m->by_name.find(name);
+    return it == m->by_name.end() ? nullptr : &m->slots[it->second];
+}
+
+void add_stack_slots(rt_model* m, const char* p, const rt_stack_dims& d, bool qk_norm, bool layer_scale) {
+    const int64_t qd = (int64_t)d.heads * d.head_dim, kvd = (int64_t)d.kv_heads * d.head_dim;
+    for (int i = 0; i < d.layers; ++i) {
+        const std::string b = std::string(p) + ".l" + std::to_string(i);
+        add_slot(m, b + ".wqkv", K_GEMM, qd + 2 * kvd, d.hidden);
+        add_slot(m, b + ".wo", K_GEMM, d.hidden, qd);
+        add_slot(m, b + ".wgu", K_GEMM, 2 * (int64_t)d.inter, d.hidden);
+        add_slot(m, b + ".wd", K_GEMM, d.hidden, d.inter);
+        add_slot(m, b + ".ln1", K_VEC, d.hidden, 1);
+        add_slot(m, b + ".ln2", K_VEC, d.hidden, 1);
+        if (qk_norm) { add_slot(m, b + ".qn", K_VEC, d.head_dim, 1); add_slot(m, b + ".kn", K_VEC, d.head_dim, 1); }
+        if (layer_scale) { add_slot(m, b + ".ls1", K_VEC, d.hidden, 1); add_slot(m, b + ".ls2", K_VEC, d.hidden, 1); }
+    }
+    add_slot(m, std::string(p) + ".norm", K_VEC, d.hidden, 1);
+}
+
+void declare_slots(rt_model* m) {
+    const rt_model_config& c = m->cfg;
+    const int H = c.talker.hidden, Hp = c.predictor.hidden, Hc = c.codec_tf.hidden;
+    add_slot(m, "talker.text_embedding", K_TABLE, c.text_vocab, c.text_hidden);
+    add_slot(m, "talker.tp_fc1", K_GEMM, c.text_hidden, c.text_hidden);
+    add_slot(m, "talker.tp_fc1_b", K_VEC, c.text_hidden, 1);
+    add_slot(m, "talker.tp_fc2", K_GEMM, H, c.text_hidden);
+    add_slot(m, "talker.tp_fc2_b", K_VEC, H, 1);
+    add_slot(m, "talker.codec_embedding", K_TABLE, c.codec_vocab, H);
+    add_slot(m, "talker.codec_head", K_GEMM, c.codec_vocab, H);
+    add_stack_slots(m, "talker", c.talker, true, false);
+    if (m->has_mtp()) { add_slot(m, "pred.mtp", K_GEMM, Hp, H); add_slot(m, "pred.mtp_b", K_VEC, Hp, 1); }
+    for (int g = 0; g < c.n_groups - 1; ++g) {
+        add_slot(m, "pred.emb" + std::to_string(g), K_TABLE, c.predictor_vocab, H);
+        add_slot(m, "pred.head" + std::to_string(g), K_GEMM, c.predictor_vocab, Hp);
+    }
+    add_stack_slots(m, "pred", c.predictor, true, false);
+    add_slot(m, "codec.code_embedding", K_TABLE, (int64_t)c.codebook_size * c.num_quantizers, Hc);
+    add_stack_slots(m, "ctf", c.codec_tf, false, true);
+    for (int i = 0; i < c.n_upsampling; ++i) {
+        const std::string u = "codec.up" + std::to_string(i);
+        const int r = c.upsampling_ratios[i];
+        add_slot(m, u + ".tconv", K_GEMM, (int64_t)r * Hc, Hc);
+        add_slot(m, u + ".tconv_b", K_VEC, (int64_t)r * Hc, 1);
+        add_slot(m, u + ".dw_w", K_VEC, 7 * (int64_t)Hc, 1);
+        add_slot(m, u + ".dw_b", K_VEC, Hc, 1);
+        add_slot(m, u + ".ln_w", K_VEC, Hc, 1);
+        add_slot(m, u + ".ln_b", K_VEC, Hc, 1);
+        add_slot(m, u + ".pw1", K_GEMM, 4 * (int64_t)Hc, Hc);
+        add_slot(m, u + ".pw1_b", K_VEC, 4 * (int64_t)Hc, 1);
+        add_slot(m, u + ".pw2", K_GEMM, Hc, 4 * (int64_t)Hc);
+        add_slot(m, u + ".pw2_b", K_VEC, Hc, 1);
+        add_slot(m, u + ".gamma", K_VEC, Hc, 1);
+    }
+    m->dec_ch.clear();
+    for (int i = 0; i <= c.n_upsample_rates; ++i) m->dec_ch.push_back(c.decoder_dim >> i);
+    add_slot(m, "codec.dec0", K_GEMM, m->dec_ch[0], 7 * (int64_t)Hc);
+    add_slot(m, "codec.dec0_b", K_VEC, m->dec_ch[0], 1);
+    for (int i = 0; i < c.n_upsample_rates; ++i) {
+        const std::string b = "codec.b" + std::to_string(i);
+        const int cin = m->dec_ch[i], cout = m->dec_ch[i + 1], r = c.upsample_rates[i];
+        add_slot(m, b + ".sa", K_VEC, cin, 1);
+        add_slot(m, b + ".sib", K_VEC, cin, 1);
+        add_slot(m, b + ".tconv", K_GEMM, (int64_t)r * cout, 2 * (int64_t)cin);
+        add_slot(m, b + ".tconv_b", K_VEC, (int64_t)r * cout, 1);
+        for (int j = 0; j < 3; ++j) {
+            const std::string u = b + ".u" + std::to_string(j);
+            add_slot(m, u + ".a1", K_VEC, cout, 1);
+            add_slot(m, u + ".ib1", K_VEC, cout, 1);
+            add_slot(m, u + ".c1", K_GEMM, cout, 7 * (int64_t)cout);
+            add_slot(m, u + ".c1_b", K_VEC, cout, 1);
+            add_slot(m, u + ".a2", K_VEC, cout, 1);
+            add_slot(m, u + ".ib2", K_VEC, cout, 1);
+            add_slot(m, u + ".c2", K_GEMM, cout, cout);
+            add_slot(m, u + ".c2_b", K_VEC, cout, 1);
+        }
+    }
+    const int cl = m->dec_ch.back();
+    add_slot(m, "codec.fin_a", K_VEC, cl, 1);
+    add_slot(m, "codec.fin_ib", K_VEC, cl, 1);
+    add_slot(m, "codec.fin_w", K_VEC, 7 * (int64_t)cl, 1);
+    add_slot(m, "codec.fin_b", K_VEC, 1, 1);
+}
+
+const PackedW& PW(rt_model* m, const std::string& n) { return find_slot(m, n)->pw; }
+float* VEC(rt_model* m, const std::string& n) { Slot* s = find_slot(m, n); return s ? s->vec : nullptr; }
+bf16_t* TBL(rt_model* m, const std::string& n) { return find_slot(m, n)->tbl; }
+
+int bind_stack(rt_model* m, StackW& S, const char* p, const rt_stack_dims& d, int slots, int max_pos, int window) {
+    S.d = d;
+    S.window = window;
+    S.L.resize(d.layers);
+    for (int i = 0; i < d.layers; ++i) {
+        const std::string b = std::string(p) + ".l" + std::to_string(i);
+        LayerW& L = S.L[i];
+        L.wqkv = PW(m, b + ".wqkv"); L.wo = PW(m, b + ".wo"); L.wgu = PW(m, b + ".wgu"); L.wd = PW(m, b + ".wd");
+        L.ln1 = VEC(m, b + ".ln1"); L.ln2 = VEC(m, b + ".ln2");
+        L.qn = VEC(m, b + ".qn"); L.kn = VEC(m, b + ".kn");
+        L.ls1 = VEC(m, b + ".ls1"); L.ls2 = VEC(m, b + ".ls2");
+    }
+    S.norm = VEC(m, std::string(p) + ".norm");
+    S.kv.layers = d.layers; S.kv.slots = slots; S.kv.kv_heads = d.kv_heads; S.kv.max_pos = max_pos; S.kv.head_dim = d.head_dim;
+    const size_t bytes = (size_t)d.layers * S.kv.layer_stride() * sizeof(bf16_t);
+    RT_HIP(m->ctx, hipMalloc((void**)&S.kv.k, bytes));
+    RT_HIP(m->ctx, hipMalloc((void**)&S.kv.v, bytes));
+    RT_HIP(m->ctx, hipMemsetAsync(S.kv.k, 0, bytes, m->ctx->stream));
+    RT_HIP(m->ctx, hipMemsetAsync(S.kv.v, 0, bytes, m->ctx->stream));
+    return RT_OK;
+}
+
+// ---- profiling brackets around weight-streaming GEMM launches
+struct ProfScope {
+    rt_model* m;
+    hipEvent_t stop = nullptr;
+    ProfScope(rt_model* mm, double bytes) : m(mm) {
+        if (!m->prof) return;
+        if (m->prof_used >= m->prof_ev.size()) {
+            if (m->prof_ev.size() >= 400000) return;
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            m->prof_ev.push_back({a, b});
+        }
+        auto& pr = m->prof_ev[m->prof_used++];
+        (void)hipEventRecord(pr.first, m->ctx->stream);
+        stop = pr.second;
+        m->prof_bytes += bytes;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, m->ctx->stream); }
+};
+
+// rows x K (bf16) times W^T -> raw f32 slabs [n_slabs][rows][N]
+int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* slabs, int* n_slabs) {
+    if (rows <= 64) {
+        const int S = skinny_pick_split(rows, W.N, W.K, m->ctx->n_cu);
+        ProfScope ps(m, (double)W.N * W.K * 2.0);
+        RT_TRY(launch_gemm_skinny(m->ctx, A, rows, W, slabs, W.N, S));
+        *n_slabs = S;
+    } else {
+        GemmA a; a.ptr = A; a.is_f32 = 0; a.M = rows; a.Cin = W.K; a.taps = 1;
+        GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = 1;
+        RT_TRY(launch_gemm(m->ctx, a, W, e));
+        *n_slabs = 1;
+    }
+    return RT_OK;
+}
+
+struct StackWs {
+    bf16_t* xn = nullptr;     // [M][H]
+    float* slabs = nullptr;   // max over GEMMs
+    float* q = nullptr;       // [M][q_dim]
+    bf16_t* ao = nullptr;     // [M][q_dim]
+    bf16_t* act = nullptr;    // [M][I]
+};
+size_t slab_floats(const rt_stack_dims& d, int M) {
+    const size_t widest = std::max<size_t>((size_t)2 * d.inter, (size_t)(d.heads + 2 * d.kv_heads) * d.head_dim);
+    return std::max<size_t>((size_t)M * widest, (size_t)64 * 32768);
+}
+int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w) {
+    RT_TRY(pool_arr(m, (size_t)M * d.hidden, &w->xn));
+    RT_TRY(pool_arr(m, slab_floats(d, M), &w->slabs));
+    RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
+    RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->ao));
+    RT_TRY(pool_arr(m, (size_t)M * d.inter, &w->act));
+    return RT_OK;
+}
+
+// x [M][H] f32 in/out (residual stream); on return out_bf16/out_f32 hold the final-norm output.
+int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
+                  bf16_t* out_bf16, float* out_f32) {
+    rt_ctx* ctx = m->ctx;
+    const rt_stack_dims& d = S.d;
+    const int H = d.hidden;
+    int ns = 0;
+    const float* pending_scale = nullptr;
+    for (int i = 0; i < d.layers; ++i) {
+        LayerW& L = S.L[i];
+        RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, L.ln1, d.rms_eps, w.xn, nullptr));
+        RT_TRY(gemm_rows(m, w.xn, M, L.wqkv, w.slabs, &ns));
+        RT_TRY(launch_qkv_post(ctx, w.slabs, ns, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
+                               pos_add, w.q, S.kv, i));
+        RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao));
+        RT_TRY(gemm_rows(m, w.ao, M, L.wo, w.slabs, &ns));
+        RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, L.ls1, L.ln2, d.rms_eps, w.xn, nullptr));
+        RT_TRY(gemm_rows(m, w.xn, M, L.wgu, w.slabs, &ns));
+        RT_TRY(launch_silu_mul(ctx, w.slabs, ns, M, d.inter, w.act));
+        RT_TRY(gemm_rows(m, w.act, M, L.wd, w.slabs, &ns));
+        pending_scale = L.ls2;
+    }
+    RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, S.norm, d.rms_eps, out_bf16, out_f32));
+    return RT_OK;
+}
+
+// text_proj(text_embedding[ids]) -> f32 [n][H]
+int text_project(rt_model* m, const int32_t* d_ids, int n, float* out) {
+    rt_ctx* ctx = m->ctx;
+    const rt_model_config& c = m->cfg;
+    bf16_t *e = nullptr, *h1 = nullptr;
+    RT_TRY(pool_arr(m, (size_t)n * c.text_hidden, &e));
+    RT_TRY(pool_arr(m, (size_t)n * c.text_hidden, &h1));
+    GatherSrc src{TBL(m, "talker.text_embedding"), c.text_hidden};
+    GatherSrc* d_src = nullptr;
+    RT_TRY(pool_arr(m, 1, &d_src));
+    RT_HIP(ctx, hipMemcpyAsync(d_src, &src, sizeof(src), hipMemcpyHostToDevice, ctx->stream));
+    RT_TRY(launch_gather_sum(ctx, d_src, 1, d_ids, n, c.text_hidden, nullptr, nullptr, nullptr, nullptr, e));
+    GemmA a; a.ptr = e; a.M = n; a.Cin = c.text_hidden;
+    GemmEpi e1; e1.bias = VEC(m, "talker.tp_fc1_b"); e1.act = ACT_SILU; e1.out_bf16 = h1; e1.ldc = c.text_hidden;
+    RT_TRY(launch_gemm(ctx, a, PW(m, "talker.tp_fc1"), e1));
+    GemmA a2; a2.ptr = h1; a2.M = n; a2.Cin = c.text_hidden;
+    GemmEpi e2; e2.bias = VEC(m, "talker.tp_fc2_b"); e2.out_f32 = out; e2.ldc = c.talker.hidden;
+    RT_TRY(launch_gemm(ctx, a2, PW(m, "talker.tp_fc2"), e2));
+    return RT_OK;
+}
+
+int expand_vec(rt_model* m, const float* src, int n, int reps, float** out) {
+    float* p = nullptr;
+    RT_HIP(m->ctx, hipMalloc((void**)&p, (size_t)n * reps * sizeof(float)));
+    for (int r = 0; r < reps; ++r)
+        RT_HIP(m->ctx, hipMemcpyAsync(p + (size_t)r * n, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, m->ctx->stream));
+    m->exp_vecs.push_back(p);
+    *out = p;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_model_create(rt_ctx* ctx, const rt_model_config* cfg, rt_model** out_model) {
+    if (!ctx || !cfg || !out_model) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_create: null argument");
+    *out_model = nullptr;
+    const rt_model_config& c = *cfg;
+    auto bad_stack = [](const rt_stack_dims& d) {
+        return d.hidden < 16 || d.hidden % 16 || d.layers < 1 || d.heads < 1 || d.kv_heads < 1 || d.heads % d.kv_heads ||
+               (d.head_dim != 32 && d.head_dim != 64 && d.head_dim != 128) || d.inter % 16 || (d.heads * d.head_dim) % 32 ||
+               (d.kv_heads * d.head_dim) % 16;
+    };
+    if (bad_stack(c.talker) || bad_stack(c.predictor) || bad_stack(c.codec_tf))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_model_create: unsupported stack dimensions (hidden/inter %% 16, head_dim in {32,64,128})");
+    if (c.n_groups < 2 || c.n_groups > 32 || c.num_quantizers < 1 || c.num_quantizers > c.n_groups || c.max_batch < 1 || c.max_batch > 64 ||
+        c.n_upsampling < 0 || c.n_upsampling > 4 || c.n_upsample_rates < 1 || c.n_upsample_rates > 8 || c.text_hidden % 16 ||
+        c.max_positions < 8 || c.max_codec_frames < 1 || (c.decoder_dim >> c.n_upsample_rates) < 8 || (c.decoder_dim >> c.n_upsample_rates) % 8)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_model_create: unsupported configuration (n_groups 2..32, max_batch 1..64, channels %% 8)");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rt_model* m = new rt_model();
+    m->ctx = ctx;
+    m->cfg = c;
+    declare_slots(m);
+    *out_model = m;
+    return RT_OK;
+}
+
+int rt_model_destroy(rt_model* m) {
+    if (!m) return RT_OK;
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : m->slots) if (s.raw) (void)hipFree(s.raw);
+    for (StackW* S : {&m->talker, &m->pred, &m->ctf}) {
+        if (S->kv.k) (void)hipFree(S->kv.k);
+        if (S->kv.v) (void)hipFree(S->kv.v);
+        if (S->cos) (void)hipFree(S->cos);
+        if (S->sin) (void)hipFree(S->sin);
+    }
+    for (auto& b : m->pool) (void)hipFree(b.p);
+    for (auto p : m->exp_vecs) (void)hipFree(p);
+    for (auto p : m->proj_emb) (void)hipFree(p);
+    if (m->proj_c0) (void)hipFree(m->proj_c0);
+    if (m->pad_t) (void)hipFree(m->pad_t);
+    if (m->d_frame_srcs) (void)hipFree(m->d_frame_srcs);
+    for (auto& e : m->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete m;
+    return RT_OK;
+}
+
+int rt_model_tensor_count(rt_model* m) { return m ? (int)m->slots.size() : -1; }
+
+int rt_model_tensor_info(rt_model* m, int32_t index, char* name, size_t name_cap, int64_t* shape2, int32_t* kind) {
+    if (!m || index < 0 || index >= (int)m->slots.size()) return RT_ERR_INVALID;
+    const Slot& s = m->slots[index];
+    if (name && name_cap) snprintf(name, name_cap, "%s", s.name.c_str());
+    if (shape2) { shape2[0] = s.rows; shape2[1] = s.cols; }
+    if (kind) *kind = s.kind;
+    return RT_OK;
+}
+
+int rt_model_set_tensor(rt_model* m, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols, int32_t on_device) {
+    if (!m || !name || !data) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_set_tensor: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    Slot* s = find_slot(m, name);
+    if (!s) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_tensor: unknown tensor '%s'", name);
+    if (s->rows * s->cols != rows * cols || (s->kind != K_VEC && (s->rows != rows || s->cols != cols)))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_tensor: '%s' expects [%lld, %lld], got [%lld, %lld]", name, (long long)s->rows,
+                       (long long)s->cols, (long long)rows, (long long)cols);
+    if (s->kind != K_VEC && dtype != RT_DTYPE_BF16) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_tensor: '%s' must be bf16", name);
+    const int64_t n = rows * cols;
+    const size_t esz = dtype == RT_DTYPE_BF16 ? 2 : 4;
+    const void* d_src = data;
+    if (!on_device) {
+        void* stage = nullptr;
+        RT_TRY(rt_ctx_scratch(ctx, (size_t)n * esz, &stage));
+        RT_HIP(ctx, hipMemcpyAsync(stage, data, (size_t)n * esz, hipMemcpyHostToDevice, ctx->stream));
+        d_src = stage;
+    }
+    if (s->raw) { RT_HIP(ctx, hipStreamSynchronize(ctx->stream)); RT_HIP(ctx, hipFree(s->raw)); s->raw = nullptr; }
+    if (s->kind == K_GEMM) {
+        const size_t pb = packed_bytes((int)rows, (int)cols);
+        RT_HIP(ctx, hipMalloc(&s->raw, pb));
+        RT_TRY(launch_pack_weight(ctx, (const bf16_t*)d_src, (int)rows, (int)cols, (bf16_t*)s->raw, &s->pw));
+        m->weight_bytes += (int64_t)pb;
+    } else if (s->kind == K_TABLE) {
+        RT_HIP(ctx, hipMalloc(&s->raw, (size_t)n * 2));
+        RT_HIP(ctx, hipMemcpyAsync(s->raw, d_src, (size_t)n * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        s->tbl = (bf16_t*)s->raw;
+        m->weight_bytes += n * 2;
+    } else {
+        RT_HIP(ctx, hipMalloc(&s->raw, (size_t)n * 4));
+        s->vec = (float*)s->raw;
+        if (dtype == RT_DTYPE_F32) RT_HIP(ctx, hipMemcpyAsync(s->raw, d_src, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        else hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+                                (const bf16_t*)d_src, n, s->vec);
+        RT_HIP(ctx, hipGetLastError());
+    }
+    if (!on_device) RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next call
+    s->set = true;
+    return RT_OK;
+}
+
+int rt_model_finalize(rt_model* m, const float* h_rope_cos[3], const float* h_rope_sin[3]) {
+    if (!m || !h_rope_cos || !h_rope_sin) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_finalize: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_model_finalize: already finalized");
+    for (auto& s : m->slots)
+        if (!s.set) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_finalize: tensor '%s' was never set", s.name.c_str());
+    const rt_model_config& c = m->cfg;
+    RT_TRY(bind_stack(m, m->talker, "talker", c.talker, c.max_batch + 1, c.max_positions, 0));
+    RT_TRY(bind_stack(m, m->pred, "pred", c.predictor, c.max_batch, c.n_groups + 1, 0));
+    RT_TRY(bind_stack(m, m->ctf, "ctf", c.codec_tf, c.max_batch, c.max_codec_frames, c.codec_sliding_window));
+    StackW* stacks[3] = {&m->talker, &m->pred, &m->ctf};
+    for (int i = 0; i < 3; ++i) {
+        StackW& S = *stacks[i];
+        const size_t n = (size_t)S.kv.max_pos * (S.d.head_dim / 2);
+        RT_HIP(ctx, hipMalloc((void**)&S.cos, n * 4));
+        RT_HIP(ctx, hipMalloc((void**)&S.sin, n * 4));
+        RT_HIP(ctx, hipMemcpy(S.cos, h_rope_cos[i], n * 4, hipMemcpyHostToDevice));
+        RT_HIP(ctx, hipMemcpy(S.sin, h_rope_sin[i], n * 4, hipMemcpyHostToDevice));
+    }
+    // frame-embedding sources: group 0 = talker codec table, group g = predictor table g-1
+    std::vector<GatherSrc> srcs(c.n_groups);
+    srcs[0] = {TBL(m, "talker.codec_embedding"), c.talker.hidden};
+    for (int gq = 1; gq < c.n_groups; ++gq) srcs[gq] = {TBL(m, "pred.emb" + std::to_string(gq - 1)), c.talker.hidden};
+    RT_HIP(ctx, hipMalloc((void**)&m->d_frame_srcs, sizeof(GatherSrc) * c.n_groups));
+    RT_HIP(ctx, hipMemcpy(m->d_frame_srcs, srcs.data(), sizeof(GatherSrc) * c.n_groups, hipMemcpyHostToDevice));
+    // projected predictor input tables: mtp(emb) for every code, so the per-frame loop is gathers only
+    if (m->has_mtp()) {
+        const int Hp = c.predictor.hidden, H = c.talker.hidden;
+        auto project = [&](const bf16_t* tbl, int rows, float** out) -> int {
+            RT_HIP(ctx, hipMalloc((void**)out, (size_t)rows * Hp * 4));
+            GemmA a; a.ptr = tbl; a.M = rows; a.Cin = H;
+            GemmEpi e; e.bias = VEC(m, "pred.mtp_b"); e.out_f32 = *out; e.ldc = Hp;
+            return launch_gemm(ctx, a, PW(m, "pred.mtp"), e);
+        };
+        RT_TRY(project(TBL(m, "talker.codec_embedding"), c.codec_vocab, &m->proj_c0));
+        m->proj_emb.resize(c.n_groups - 1, nullptr);
+        for (int gq = 0; gq < c.n_groups - 1; ++gq) RT_TRY(project(TBL(m, "pred.emb" + std::to_string(gq)), c.predictor_vocab, &m->proj_emb[gq]));
+    }
+    // SnakeBeta parameters of each block's first residual unit, tiled over the r output phases of the transposed conv
+    for (int i = 0; i < c.n_upsample_rates; ++i) {
+        const std::string bn = "codec.b" + std::to_string(i);
+        for (const char* v : {".u0.a1", ".u0.ib1"}) {
+            float* x = nullptr;
+            RT_TRY(expand_vec(m, VEC(m, bn + v), m->dec_ch[i + 1], c.upsample_rates[i], &x));
+            m->xvec[bn + v] = x;
+        }
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->finalized = true;
+    return RT_OK;
+}
+
+int64_t rt_model_weight_bytes(rt_model* m) { return m ? m->weight_bytes : -1; }
+
+int rt_profile_enable(rt_model* m, int32_t on) {
+    if (!m) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> g(m->ctx->mu);
+    m->prof = on != 0;
+    m->prof_used = 0;
+    m->prof_bytes = 0;
+    return RT_OK;
+}
+
+int rt_profile_read(rt_model* m, int64_t* n_launches, double* total_ms, double* total_bytes) {
+    if (!m) return RT_ERR_INVALID;
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0;
+    for (size_t i = 0; i < m->prof_used; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, m->prof_ev[i].first, m->prof_ev[i].second) == hipSuccess) ms += t;
+    }
+    if (n_launches) *n_launches = (int64_t)m->prof_used;
+    if (total_ms) *total_ms = ms;
+    if (total_bytes) *total_bytes = m->prof_bytes;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ voice
+int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids, int32_t h_speaker_row,
+                       const float* h_speaker_embed) {
+    if (!m || n_rows < 1 || !h_text_ids || !h_codec_ids) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_set_voice: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_model_set_voice: model not finalized");
+    const rt_model_config& c = m->cfg;
+    if (n_rows + 8 > c.max_positions) return rt_fail(ctx, RT_ERR_LENGTH, "voice prefix length %d exceeds max_positions %d", n_rows, c.max_positions);
+    if (h_speaker_row >= n_rows || (h_speaker_row >= 0 && !h_speaker_embed)) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_voice: bad speaker row");
+    const int H = c.talker.hidden, G = c.n_groups;
+    for (int r = 0; r < n_rows; ++r) {
+        if (h_text_ids[r] < 0 || h_text_ids[r] >= c.text_vocab) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_voice: text id %d out of range", h_text_ids[r]);
+        for (int q = 0; q < G; ++q) {
+            const int id = h_codec_ids[r * G + q];
+            if (id >= (q == 0 ? c.codec_vocab : c.predictor_vocab)) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_voice: codec id %d out of range", id);
+        }
+    }
+    pool_release_all(m);
+    // text side: project every row that has a text id (rows without one get -1 -> no text term... they get tts_pad by contract)
+    int32_t *d_tid = nullptr, *d_cid = nullptr, *d_slot = nullptr, *d_pos = nullptr;
+    RT_TRY(pool_arr(m, n_rows, &d_tid));
+    RT_TRY(pool_arr(m, (size_t)n_rows * G, &d_cid));
+    RT_TRY(pool_arr(m, n_rows, &d_slot));
+    RT_TRY(pool_arr(m, n_rows, &d_pos));
+    std::vector<int32_t> tid(h_text_ids, h_text_ids + n_rows);
+    RT_HIP(ctx, hipMemcpyAsync(d_tid, tid.data(), n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_cid, h_codec_ids, (size_t)n_rows * G * 4, hipMemcpyHostToDevice, ctx->stream));
+    float* temb = nullptr;  // [n_rows + 1][H]: projected text rows, then the speaker vector
+    RT_TRY(pool_arr(m, (size_t)(n_rows + 1) * H, &temb));
+    RT_TRY(text_project(m, d_tid, n_rows, temb));
+    float* x = nullptr;
+    RT_TRY(pool_arr(m, (size_t)n_rows * H, &x));
+    RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_cid, n_rows, H, nullptr, temb, nullptr, x, nullptr));
+    if (h_speaker_row >= 0) {
+        float* spk = temb + (size_t)n_rows * H;
+        RT_HIP(ctx, hipMemcpyAsync(spk, h_speaker_embed, H * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_add_vec, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, x + (size_t)h_speaker_row * H, spk, H);
+        RT_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(8), dim3(256), 0, ctx->stream, d_slot, n_rows, m->prefix_slot(), 0, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3(8), dim3(256), 0, ctx->stream, d_pos, n_rows, 0, 1, 1);
+    RT_HIP(ctx, hipGetLastError());
+    StackWs w;
+    RT_TRY(alloc_stack_ws(m, c.talker, n_rows, &w));
+    bf16_t* hn = nullptr;
+    RT_TRY(pool_arr(m, (size_t)n_rows * H, &hn));
+    RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->prefix_len = n_rows;
+    pool_release_all(m);
+    return RT_OK;
+}
+
+int32_t rt_voice_prefix_len(rt_model* m) { return m ? m->prefix_len : -1; }
+
+int64_t rt_voice_blob_bytes(rt_model* m) {
+    if (!m) return -1;
+    const rt_stack_dims& d = m->cfg.talker;
+    return (int64_t)2 * d.layers * d.kv_heads * m->prefix_len * d.head_dim * 2;
+}
+
+static int voice_blob(rt_model* m, void* d_blob, int64_t bytes, int to_blob, int prefix_len) {
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "voice blob: model not finalized");
+    const rt_stack_dims& d = m->cfg.talker;
+    if (prefix_len < 1 || prefix_len + 8 > m->cfg.max_positions) return rt_fail(ctx, RT_ERR_LENGTH, "voice blob: prefix length %d out of range", prefix_len);
+    const int64_t need = (int64_t)2 * d.layers * d.kv_heads * prefix_len * d.head_dim * 2;
+    if (!d_blob || bytes != need) return rt_fail(ctx, RT_ERR_INVALID, "voice blob: expected %lld bytes, got %lld", (long long)need, (long long)bytes);
+    KvCache& kv = m->talker.kv;
+    hipLaunchKernelGGL(k_kv_blob, dim3(d.layers * d.kv_heads, 2), dim3(256), 0, ctx->stream, kv.k, kv.v, (int64_t)kv.layer_stride(), d.layers,
+                       d.kv_heads, kv.max_pos, d.head_dim, m->prefix_slot(), prefix_len, (bf16_t*)d_blob, to_blob);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!to_blob) m->prefix_len = prefix_len;
+    return RT_OK;
+}
+int rt_voice_export(rt_model* m, void* d_blob, int64_t bytes) {
+    if (!m) return RT_ERR_INVALID;
+    return voice_blob(m, d_blob, bytes, 1, m->prefix_len);
+}
+int rt_voice_import(rt_model* m, int32_t prefix_len, const void* d_blob, int64_t bytes) {
+    if (!m) return RT_ERR_INVALID;
+    return voice_blob(m, const_cast<void*>(d_blob), bytes, 0, prefix_len);
+}
+
+// --------------------------------------------------------------------------------------- generate
+int rt_generate(rt_model* m, const rt_generate_args* A) {
+    if (!m || !A) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_generate: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_generate: model not finalized");
+    if (m->prefix_len < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: no voice set (rt_model_set_voice)");
+    const rt_model_config& c = m->cfg;
+    const int B = A->n_items, G = c.n_groups, H = c.talker.hidden, Hp = c.predictor.hidden, Vc = c.codec_vocab, Vp = c.predictor_vocab;
+    if (B < 1 || B > c.max_batch) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: n_items %d outside 1..%d", B, c.max_batch);
+    if (!A->h_text_ids || !A->h_text_offsets || !A->h_max_frames || !A->h_item_ids || !A->h_codes || !A->h_n_frames)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: null array");
+    int T_max = 0, n_suffix = 0, max_suffix = 0;
+    for (int b = 0; b < B; ++b) {
+        const int nt = A->h_text_offsets[b + 1] - A->h_text_offsets[b];
+        if (nt < 0 || A->h_max_frames[b] < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: item %d has bad text or max_frames", b);
+        T_max = std::max(T_max, A->h_max_frames[b]);
+        n_suffix += nt + 2;
+        max_suffix = std::max(max_suffix, nt + 2);
+    }
+    for (int i = 0; i < A->h_text_offsets[B]; ++i)
+        if (A->h_text_ids[i] < 0 || A->h_text_ids[i] >= c.text_vocab) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: text id out of range");
+    const int Lp = m->prefix_len;
+    if (Lp + max_suffix + T_max + 1 > c.max_positions)
+        return rt_fail(ctx, RT_ERR_LENGTH, "rt_generate: prompt length %d + %d frames exceeds max_positions %d", Lp + max_suffix, T_max, c.max_positions);
+    if (A->talker.do_sample && (A->talker.top_k < 1 || A->talker.top_k > 64 || !(A->talker.temperature > 0)))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: sampling needs 1 <= top_k <= 64 and temperature > 0");
+    if (A->predictor.do_sample && (A->predictor.top_k < 1 || A->predictor.top_k > 64 || !(A->predictor.temperature > 0)))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: predictor sampling needs 1 <= top_k <= 64 and temperature > 0");
+    pool_release_all(m);
+
+    // ---- fan the voice prefix KV out to the B sequence slots
+    {
+        KvCache& kv = m->talker.kv;
+        hipLaunchKernelGGL(k_kv_fanout, dim3(c.talker.layers * c.talker.kv_heads, B), dim3(256), 0, ctx->stream, kv.k, kv.v,
+                           (int64_t)kv.layer_stride(), c.talker.kv_heads, kv.max_pos, c.talker.head_dim, m->prefix_slot(), Lp);
+        RT_HIP(ctx, hipGetLastError());
+    }
+    // ---- suffix rows: [text tokens + tts_eos] x codec_pad, then (tts_pad, codec_bos)
+    std::vector<int32_t> s_tid(n_suffix + 1), s_cid((size_t)n_suffix * G, -1), s_slot(n_suffix), s_pos(n_suffix), last_row(B), P(B);
+    int r = 0;
+    for (int b = 0; b < B; ++b) {
+        const int o = A->h_text_offsets[b], nt = A->h_text_offsets[b + 1] - o;
+        for (int j = 0; j < nt + 2; ++j, ++r) {
+            s_tid[r] = j < nt ? A->h_text_ids[o + j] : (j == nt ? A->tts_eos_id : A->tts_pad_id);
+            s_cid[(size_t)r * G] = j <= nt ? A->codec_pad_id : A->codec_bos_id;
+            s_slot[r] = b;
+            s_pos[r] = Lp + j;
+        }
+        last_row[b] = r - 1;
+        P[b] = Lp + nt + 2;
+    }
+    s_tid[n_suffix] = A->tts_pad_id;  // extra row: projected tts_pad, added to every decode-step input
+    int32_t *d_tid, *d_cid, *d_slot, *d_pos, *d_last;
+    RT_TRY(pool_arr(m, n_suffix + 1, &d_tid));
+    RT_TRY(pool_arr(m, (size_t)n_suffix * G, &d_cid));
+    RT_TRY(pool_arr(m, n_suffix, &d_slot));
+    RT_TRY(pool_arr(m, n_suffix, &d_pos));
+    RT_TRY(pool_arr(m, B, &d_last));
+    RT_HIP(ctx, hipMemcpyAsync(d_tid, s_tid.data(), (n_suffix + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_cid, s_cid.data(), (size_t)n_suffix * G * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_slot, s_slot.data(), n_suffix * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_pos, s_pos.data(), n_suffix * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_last, last_row.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
+    float *temb, *x, *hn_all_f32;
+    RT_TRY(pool_arr(m, (size_t)(n_suffix + 1) * H, &temb));
+    RT_TRY(text_project(m, d_tid, n_suffix + 1, temb));
+    const float* pad_t = temb + (size_t)n_suffix * H;
+    RT_TRY(pool_arr(m, (size_t)n_suffix * H, &x));
+    RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_cid, n_suffix, H, nullptr, temb, nullptr, x, nullptr));
+    RT_TRY(pool_arr(m, (size_t)n_suffix * H, &hn_all_f32));
+    {
+        StackWs w;
+        RT_TRY(alloc_stack_ws(m, c.talker, n_suffix, &w));
+        RT_TRY(stack_forward(m, m->talker, w, x, n_suffix, d_slot, d_pos, 0, nullptr, hn_all_f32));
+    }
+    // ---- decode state
+    const int B2 = 2 * B;
+    float *xt, *hn_f32, *xp, *logits;
+    bf16_t *hn, *hn_p;
+    int32_t *d_codes, *d_eos, *d_slot_b, *d_pos_b, *d_pos_p2, *d_zero_pos, *d_forced = nullptr, *d_tmp_idx;
+    int64_t* d_items;
+    uint8_t* d_seen;
+    RT_TRY(pool_arr(m, (size_t)B * H, &xt));
+    RT_TRY(pool_arr(m, (size_t)B * H, &hn_f32));
+    RT_TRY(pool_arr(m, (size_t)B * H, &hn));
+    RT_TRY(pool_arr(m, (size_t)B2 * Hp, &xp));
+    RT_TRY(pool_arr(m, (size_t)B2 * Hp, &hn_p));
+    RT_TRY(pool_arr(m, (size_t)64 * 32768, &logits));
+    RT_TRY(pool_arr(m, (size_t)T_max * B * G, &d_codes));
+    RT_TRY(pool_arr(m, (size_t)T_max * B, &d_eos));
+    RT_TRY(pool_arr(m, B2, &d_slot_b));
+    RT_TRY(pool_arr(m, B, &d_pos_b));
+    RT_TRY(pool_arr(m, B2, &d_pos_p2));
+    RT_TRY(pool_arr(m, B2, &d_zero_pos));
+    RT_TRY(pool_arr(m, B2, &d_tmp_idx));
+    RT_TRY(pool_arr(m, B, &d_items));
+    RT_TRY(pool_arr(m, (size_t)B * Vc, &d_seen));
+    RT_HIP(ctx, hipMemsetAsync(d_seen, 0, (size_t)B * Vc, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(d_codes, 0, (size_t)T_max * B * G * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(d_eos, 0, (size_t)T_max * B * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(d_zero_pos, 0, B2 * 4, ctx->stream));
+    {
+        std::vector<int32_t> sl(B2), p2(B2);
+        for (int b = 0; b < B; ++b) { sl[b] = b; sl[B + b] = b; p2[b] = 0; p2[B + b] = 1; }
+        RT_HIP(ctx, hipMemcpyAsync(d_slot_b, sl.data(), B2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_pos_p2, p2.data(), B2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_pos_b, P.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_items, A->h_item_ids, B * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    std::vector<int32_t> forced_host;
+    if (A->h_forced_codes) {
+        if (!A->h_forced_offsets) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: forced codes without offsets");
+        forced_host.assign((size_t)T_max * G * B, -1);  // layout [t][g][b]
+        for (int b = 0; b < B; ++b) {
+            const int o = A->h_forced_offsets[b], nf = A->h_forced_offsets[b + 1] - o;
+            for (int t = 0; t < T_max; ++t) {
+                if (nf <= 0) continue;
+                const int ts = t < nf ? t : nf - 1;                      // predictor groups reuse the last forced frame
+                for (int q = 0; q < G; ++q) {
+                    if (q == 0 && t >= nf) continue;                     // group 0 is only forced while frames remain
+                    forced_host[((size_t)t * G + q) * B + b] = A->h_forced_codes[((size_t)o + ts) * G + q];
+                }
+            }
+        }
+        RT_TRY(pool_arr(m, forced_host.size(), &d_forced));
+        RT_HIP(ctx, hipMemcpyAsync(d_forced, forced_host.data(), forced_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // hn <- final-norm rows of each item's last prompt position
+    RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
+    StackWs wt, wp;
+    RT_TRY(alloc_stack_ws(m, c.talker, B, &wt));
+    RT_TRY(alloc_stack_ws(m, c.predictor, B2, &wp));
+    const PackedW& head = PW(m, "talker.codec_head");
+
+    std::vector<int32_t> eos_host((size_t)T_max * B, 0);
+    std::vector<char> done(B, 0);
+    std::vector<int> produced(B, 0);
+    int frames_run = 0;
+    bool cancelled = false;
+    for (int t = 0; t < T_max; ++t) {
+        if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
+        int32_t* codes_t = d_codes + (size_t)t * B * G;
+        int ns = 0;
+        // ---- group 0 from the talker state
+        RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
+        SampleArgs sa{};
+        sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
+        sa.do_sample = A->talker.do_sample; sa.temperature = A->talker.temperature; sa.top_k = A->talker.top_k; sa.top_p = A->talker.top_p;
+        sa.rep_penalty = A->talker.repetition_penalty; sa.seen = d_seen;
+        sa.suppress_from = c.codebook_size;
+        sa.allow_token = (!A->ignore_eos && t >= A->min_frames) ? c.codec_eos_id : -1;
+        sa.seed = A->seed; sa.item_ids = d_items; sa.frame = t; sa.group = 0;
+        sa.forced = d_forced ? d_forced + ((size_t)t * G + 0) * B : nullptr;
+        sa.out = codes_t; sa.out_stride = G; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos + (size_t)t * B;
+        sa.logits_copy = A->d_trace_talker ? A->d_trace_talker + (size_t)t * B * Vc : nullptr;
+        RT_TRY(launch_sample(ctx, sa));
+        // ---- predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
+        if (m->has_mtp()) {
+            RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
+            RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
+        }
+        // (index extraction) codes_t has stride G; build a dense index vector with a tiny strided copy
+        RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
+        if (m->has_mtp()) {
+            RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_tmp_idx, B, xp + (size_t)B * Hp, nullptr));
+        } else {
+            RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr));
+        }
+        RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
+        for (int q = 0; q < G - 1; ++q) {
+            const bf16_t* hrow = (q == 0) ? hn_p + (size_t)B * Hp : hn_p;
+            RT_TRY(gemm_rows(m, hrow, B, PW(m, "pred.head" + std::to_string(q)), logits, &ns));
+            SampleArgs sp{};
+            sp.logits = logits; sp.n_slabs = ns; sp.M = B; sp.V = Vp;
+            sp.do_sample = A->predictor.do_sample; sp.temperature = A->predictor.temperature; sp.top_k = A->predictor.top_k;
+            sp.top_p = A->predictor.top_p; sp.rep_penalty = 1.0f; sp.seen = nullptr; sp.suppress_from = Vp; sp.allow_token = -1;
+            sp.seed = A->seed; sp.item_ids = d_items; sp.frame = t; sp.group = q + 1;
+            sp.forced = d_forced ? d_forced + ((size_t)t * G + q + 1) * B : nullptr;
+            sp.out = codes_t + q + 1; sp.out_stride = G; sp.eos_token = -1; sp.eos_flag = nullptr;
+            sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + (((size_t)t * (G - 1) + q) * B) * Vp : nullptr;
+            RT_TRY(launch_sample(ctx, sp));
+            if (q < G - 2) {
+                RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t + q + 1, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
+                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_tmp_idx, B, xp, nullptr));
+                else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp, nullptr));
+                RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
+            }
+        }
+        frames_run = t + 1;
+        // ---- stop bookkeeping (needs the eos flags on the host only when eos is live)
+        bool all_done = true;
+        if (!A->ignore_eos) {
+            RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)t * B, d_eos + (size_t)t * B, B * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        for (int b = 0; b < B; ++b) {
+            if (!done[b]) {
+                if (eos_host[(size_t)t * B + b]) done[b] = 1;
+                else if (++produced[b] >= A->h_max_frames[b]) done[b] = 1;
+            }
+            all_done = all_done && done[b];
+        }
+        if (all_done) break;
+        // ---- next talker input: sum of the frame's G code embeddings + projected tts_pad
+        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes_t, B, H, pad_t, nullptr, nullptr, xt, nullptr));
+        RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, t, hn, hn_f32));
+    }
+    // ---- results
+    std::vector<int32_t> codes_host((size_t)std::max(frames_run, 1) * B * G);
+    if (frames_run > 0) {
+        RT_HIP(ctx, hipMemcpyAsync(codes_host.data(), d_codes, (size_t)frames_run * B * G * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pool_release_all(m);
+    if (cancelled) return rt_fail(ctx, RT_ERR_CANCELLED, "rt_generate: cancelled after %d frames", frames_run);
+    size_t off = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n = std::min(produced[b], frames_run);
+        A->h_n_frames[b] = n;
+        for (int t = 0; t < n; ++t)
+            for (int q = 0; q < G; ++q) A->h_codes[(off + t) * G + q] = codes_host[((size_t)t * B + b) * G + q];
+        off += A->h_max_frames[b];
+    }
+    return RT_OK;
+}
+
+// --------------------------------------------------------------------------------------- code2wav
+int64_t rt_wav_length(rt_model* m, int32_t n_frames) {
+    if (!m || n_frames < 0) return -1;
+    int64_t L = n_frames;
+    for (int i = 0; i < m->cfg.n_upsampling; ++i) L *= m->cfg.upsampling_ratios[i];
+    for (int i = 0; i < m->cfg.n_upsample_rates; ++i) L = (L - 1) * m->cfg.upsample_rates[i];
+    return L > 0 ? L : 0;
+}
+
+int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_codes, const int32_t* h_n_frames, float* d_wav,
+                int64_t wav_stride, int64_t* h_wav_len) {
+    if (!m || !h_codes || !h_n_frames || !d_wav || !h_wav_len) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_code2wav: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_code2wav: model not finalized");
+    const rt_model_config& c = m->cfg;
+    const int B = n_items, T = t_max, Q = c.num_quantizers, Hc = c.codec_tf.hidden;
+    if (B < 1 || B > c.max_batch || T < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_code2wav: n_items %d / t_max %d out of range", B, T);
+    if (T > c.max_codec_frames) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: length %d frames exceeds max_codec_frames %d", T, c.max_codec_frames);
+    const int64_t L_out = rt_wav_length(m, T);
+    if (L_out < 1) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: length %d frames too short for the decoder", T);
+    if (wav_stride < L_out) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: wav_stride %lld < length %lld", (long long)wav_stride, (long long)L_out);
+    for (int b = 0; b < B; ++b)
+        if (h_n_frames[b] < 0 || h_n_frames[b] > T) return rt_fail(ctx, RT_ERR_INVALID, "rt_code2wav: n_frames[%d] out of range", b);
+    pool_release_all(m);
+    const int64_t rows0 = (int64_t)B * T;
+    int32_t *d_codes, *d_slot, *d_pos;
+    RT_TRY(pool_arr(m, (size_t)rows0 * Q, &d_codes));
+    RT_TRY(pool_arr(m, rows0, &d_slot));
+    RT_TRY(pool_arr(m, rows0, &d_pos));
+    RT_HIP(ctx, hipMemcpyAsync(d_codes, h_codes, (size_t)rows0 * Q * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        std::vector<int32_t> sl(rows0), ps(rows0);
+        for (int b = 0; b < B; ++b) for (int t = 0; t < T; ++t) { sl[(size_t)b * T + t] = b; ps[(size_t)b * T + t] = t; }
+        RT_HIP(ctx, hipMemcpyAsync(d_slot, sl.data(), rows0 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_pos, ps.data(), rows0 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    }
+    float* h = nullptr;
+    RT_TRY(pool_arr(m, (size_t)rows0 * Hc, &h));
+    RT_TRY(launch_code_embed_mean(ctx, TBL(m, "codec.code_embedding"), c.codebook_size, Q, Hc, d_codes, rows0, h));
+    float* hn = nullptr;
+    RT_TRY(pool_arr(m, (size_t)rows0 * Hc, &hn));
+    {
+        StackWs w;
+        RT_TRY(alloc_stack_ws(m, c.codec_tf, (int)rows0, &w));
+        RT_TRY(stack_forward(m, m->ctf, w, h, (int)rows0, d_slot, d_pos, 0, nullptr, hn));
+    }
+    // ---- ConvNeXt upsampling stages (transposed conv k = stride = r is a plain GEMM in channels-last)
+    float* cur = hn;
+    int64_t Tc = T;
+    for (int i = 0; i < c.n_upsampling; ++i) {
+        const std::string u = "codec.up" + std::to_string(i);
+        const int r = c.upsampling_ratios[i];
+        float* up = nullptr;
+        RT_TRY(pool_arr(m, (size_t)B * Tc * r * Hc, &up));
+        GemmA a; a.ptr = cur; a.is_f32 = 1; a.M = (int64_t)B * Tc; a.Cin = Hc;
+        GemmEpi e; e.bias = VEC(m, u + ".tconv_b"); e.out_f32 = up; e.ldc = (int64_t)r * Hc;
+        RT_TRY(launch_gemm(ctx, a, PW(m, u + ".tconv"), e));
+        Tc *= r;
+        const int64_t rows = (int64_t)B * Tc;
+        bf16_t *ln = nullptr, *mid = nullptr;
+        RT_TRY(pool_arr(m, (size_t)rows * Hc, &ln));
+        RT_TRY(pool_arr(m, (size_t)rows * 4 * Hc, &mid));
+        RT_TRY(launch_dwconv_ln(ctx, up, B, (int)Tc, Hc, VEC(m, u + ".dw_w"), VEC(m, u + ".dw_b"), VEC(m, u + ".ln_w"), VEC(m, u + ".ln_b"), 1e-6f, ln));
+        GemmA a1; a1.ptr = ln; a1.M = rows; a1.Cin = Hc;
+        GemmEpi e1; e1.bias = VEC(m, u + ".pw1_b"); e1.act = ACT_GELU; e1.out_bf16 = mid; e1.ldc = 4 * (int64_t)Hc;
+        RT_TRY(launch_gemm(ctx, a1, PW(m, u + ".pw1"), e1));
+        GemmA a2; a2.ptr = mid; a2.M = rows; a2.Cin = 4 * Hc;
+        GemmEpi e2; e2.bias = VEC(m, u + ".pw2_b"); e2.scale = VEC(m, u + ".gamma"); e2.residual = up; e2.out_f32 = up; e2.ldc = Hc;
+        RT_TRY(launch_gemm(ctx, a2, PW(m, u + ".pw2"), e2));
+        cur = up;
+    }
+    // ---- decoder: conv k7 -> [SnakeBeta, transposed conv, 3 residual units] x n -> SnakeBeta -> conv k7 -> clamp
+    bf16_t* s_in = nullptr;  // snake-activated input of the next transposed conv
+    {
+        RT_TRY(pool_arr(m, (size_t)B * Tc * m->dec_ch[0], &s_in));
+        GemmA a; a.ptr = cur; a.is_f32 = 1; a.M = (int64_t)B * Tc; a.Cin = Hc; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
+        a.rows_out = (int)Tc; a.rows_in = (int)Tc;
+        GemmEpi e; e.bias = VEC(m, "codec.dec0_b"); e.out2_bf16 = s_in; e.snake2_a = VEC(m, "codec.b0.sa"); e.snake2_ib = VEC(m, "codec.b0.sib");
+        e.ldc = m->dec_ch[0];
+        RT_TRY(launch_gemm(ctx, a, PW(m, "codec.dec0"), e));
+    }
+    for (int i = 0; i < c.n_upsample_rates; ++i) {
+        const std::string bn = "codec.b" + std::to_string(i);
+        const int cin = m->dec_ch[i], cout = m->dec_ch[i + 1], r = c.upsample_rates[i];
+        const int64_t To = (Tc - 1) * r;
+        if (To < 1) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: length collapsed in decoder block %d", i);
+        const int64_t rows = (int64_t)B * To;
+        float* xr = nullptr;
+        bf16_t *s1 = nullptr, *s2 = nullptr;
+        RT_TRY(pool_arr(m, (size_t)rows * cout, &xr));
+        RT_TRY(pool_arr(m, (size_t)rows * cout, &s1));
+        RT_TRY(pool_arr(m, (size_t)rows * cout, &s2));
+        {
+            // transposed conv k = 2r, stride r, r samples trimmed on both sides: out[m*r + j] = x[m+1] W[j] + x[m] W[j + r]
+            GemmA a; a.ptr = s_in; a.M = (int64_t)B * (Tc - 1); a.Cin = cin; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
+            a.rows_out = (int)(Tc - 1); a.rows_in = (int)Tc;
+            float *a1x = m->xvec[bn + ".u0.a1"], *ib1x = m->xvec[bn + ".u0.ib1"];
+            GemmEpi e; e.bias = VEC(m, bn + ".tconv_b"); e.out_f32 = xr; e.out2_bf16 = s1; e.snake2_a = a1x; e.snake2_ib = ib1x;
+            e.ldc = (int64_t)r * cout;
+            RT_TRY(launch_gemm(ctx, a, PW(m, bn + ".tconv"), e));
+        }
+        for (int j = 0; j < 3; ++j) {
+            const std::string u = bn + ".u" + std::to_string(j);
+            const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
+            GemmA a; a.ptr = s1; a.M = rows; a.Cin = cout; a.taps = 7; a.tap_stride = dil; a.tap_offset = -6 * dil;
+            a.rows_out = (int)To; a.rows_in = (int)To;
+            GemmEpi e; e.bias = VEC(m, u + ".c1_b"); e.act = ACT_SNAKE; e.snake_a = VEC(m, u + ".a2"); e.snake_ib = VEC(m, u + ".ib2");
+            e.out_bf16 = s2; e.ldc = cout;
+            RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e));
+            GemmA a2; a2.ptr = s2; a2.M = rows; a2.Cin = cout;
+            GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_bf16 = s1; e2.ldc = cout;
+            if (j < 2) { e2.snake2_a = VEC(m, bn + ".u" + std::to_string(j + 1) + ".a1"); e2.snake2_ib = VEC(m, bn + ".u" + std::to_string(j + 1) + ".ib1"); }
+            else if (i + 1 < c.n_upsample_rates) { e2.snake2_a = VEC(m, "codec.b" + std::to_string(i + 1) + ".sa"); e2.snake2_ib = VEC(m, "codec.b" + std::to_string(i + 1) + ".sib"); }
+            else { e2.snake2_a = VEC(m, "codec.fin_a"); e2.snake2_ib = VEC(m, "codec.fin_ib"); }
+            RT_TRY(launch_gemm(ctx, a2, PW(m, u + ".c2"), e2));
+        }
+        s_in = s1;
+        Tc = To;
+    }
+    float* wav_tmp = nullptr;
+    RT_TRY(pool_arr(m, (size_t)B * Tc, &wav_tmp));
+    float fin_b = 0.f;
+    RT_HIP(ctx, hipMemcpyAsync(&fin_b, VEC(m, "codec.fin_b"), 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_TRY(launch_final_conv(ctx, s_in, B, (int)Tc, m->dec_ch.back(), VEC(m, "codec.fin_w"), fin_b, wav_tmp));
+    RT_HIP(ctx, hipMemcpy2DAsync(d_wav, (size_t)wav_stride * 4, wav_tmp, (size_t)Tc * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) h_wav_len[b] = rt_wav_length(m, h_n_frames[b]);
+    pool_release_all(m);
+    return RT_OK;
+}
+
+}  // extern "C"

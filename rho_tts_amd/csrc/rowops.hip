@@ -1,0 +1,345 @@
+// Row-wise / elementwise kernels of the decode step and the codec decoder (gfx950).
+// All are HBM/L2-streaming: vectorised where the layout allows, one wave-shuffle reduction per row.
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+
+__device__ __forceinline__ float block_sum_f32(float v, float* sh) {
+    v = wave_sum_f32(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+// x += scale * (sum_s slab[s] + slab_bias); xn = rmsnorm(x) * w.   One workgroup (256) per row.
+__global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int H, const float* __restrict__ slabs, int n_slabs,
+                                                     int64_t slab_stride, const float* __restrict__ slab_bias,
+                                                     const float* __restrict__ scale, const float* __restrict__ w, float eps,
+                                                     bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    float* xr = x + row * H;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = xr[i];
+        if (n_slabs > 0) {
+            float a = slab_bias ? slab_bias[i] : 0.f;
+            for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + row * H + i];
+            if (scale) a *= scale[i];
+            v += a;
+            xr[i] = v;
+        }
+        ss += v * v;
+    }
+    if (!w) return;
+    const float tot = block_sum_f32(ss, sh);
+    const float inv = rsqrtf(tot / (float)H + eps);
+    for (int i = threadIdx.x; i < H; i += 256) {
+        const float v = w[i] * (xr[i] * inv);
+        if (out_bf16) out_bf16[row * H + i] = f32_to_bf16(v);
+        if (out_f32) out_f32[row * H + i] = v;
+    }
+}
+
+__global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
+                           int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / I;
+        const int i = (int)(idx - m * I);
+        float g = 0.f, u = 0.f;
+        for (int s = 0; s < n_slabs; ++s) {
+            const float* p = slabs + s * slab_stride + m * 2 * I;
+            g += p[i];
+            u += p[I + i];
+        }
+        out[idx] = f32_to_bf16(g / (1.f + __expf(-g)) * u);
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int N, const float* __restrict__ bias,
+                               int act, float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        float v = bias ? bias[idx % N] : 0.f;
+        for (int s = 0; s < n_slabs; ++s) v += slabs[s * slab_stride + idx];
+        if (act == ACT_SILU) v = v / (1.f + __expf(-v));
+        else if (act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        if (out_f32) out_f32[idx] = v;
+        if (out_bf16) out_bf16[idx] = f32_to_bf16(v);
+    }
+}
+
+// One wave per (row, head): sum split-K slabs, RMSNorm over head_dim, rotate-half RoPE; q -> f32 buffer,
+// k/v -> bf16 cache row (slot, pos).  head index < heads: q; < heads+kv: k; else v.
+__global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int heads,
+                                                 int kv_heads, int d, const float* __restrict__ qw, const float* __restrict__ kw,
+                                                 float eps, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                 const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
+                                                 int pos_add, float* __restrict__ q_out, bf16_t* __restrict__ kc,
+                                                 bf16_t* __restrict__ vc, int max_pos) {
+    const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+    const int width = (heads + 2 * kv_heads) * d;
+    const int half = d >> 1;
+    const int pos = row_pos[row] + pos_add, slot = row_slot[row];
+    // lane handles element pairs (i, i + half) for i = lane, lane+64, ...  (half <= 64 for d <= 128)
+    float a = 0.f, b = 0.f;
+    const bool act = lane < half;
+    if (act) {
+        const int64_t base = (int64_t)row * width + hd * d;
+        for (int s = 0; s < n_slabs; ++s) {
+            a += slabs[s * slab_stride + base + lane];
+            b += slabs[s * slab_stride + base + lane + half];
+        }
+    }
+    const bool is_q = hd < heads, is_k = !is_q && hd < heads + kv_heads;
+    if (is_q || is_k) {
+        const float* nw = is_q ? qw : kw;
+        if (nw) {
+            const float ss = wave_sum_f32(act ? a * a + b * b : 0.f);
+            const float inv = rsqrtf(ss / (float)d + eps);
+            if (act) { a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv); }
+        }
+        if (act) {
+            const float c = cosT[(int64_t)pos * half + lane], s = sinT[(int64_t)pos * half + lane];
+            const float ra = a * c - b * s, rb = b * c + a * s;
+            a = ra; b = rb;
+        }
+    }
+    if (!act) return;
+    if (is_q) {
+        float* o = q_out + ((int64_t)row * heads + hd) * d;
+        o[lane] = a;
+        o[lane + half] = b;
+    } else {
+        const int kh = is_k ? hd - heads : hd - heads - kv_heads;
+        bf16_t* o = (is_k ? kc : vc) + (((int64_t)slot * kv_heads + kh) * max_pos + pos) * d;
+        o[lane] = f32_to_bf16(a);
+        o[lane + half] = f32_to_bf16(b);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_sum(const GatherSrc* __restrict__ srcs, int n_src, const int32_t* __restrict__ idx,
+                                                    int H, const float* __restrict__ add_vec, const float* __restrict__ add_rows,
+                                                    const int32_t* __restrict__ add_row_idx, float* __restrict__ out_f32,
+                                                    bf16_t* __restrict__ out_bf16) {
+    const int64_t row = blockIdx.x;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = add_vec ? add_vec[i] : 0.f;
+        if (add_rows) {
+            const int ar = add_row_idx ? add_row_idx[row] : (int)row;
+            if (ar >= 0) v += add_rows[(int64_t)ar * H + i];
+        }
+        for (int j = 0; j < n_src; ++j) {
+            const int id = idx[row * n_src + j];
+            if (id >= 0) v += bf16_to_f32(srcs[j].table[(int64_t)id * srcs[j].row_stride + i]);
+        }
+        if (out_f32) out_f32[row * H + i] = v;
+        if (out_bf16) out_bf16[row * H + i] = f32_to_bf16(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_f32(const float* __restrict__ table, int H, const int32_t* __restrict__ idx,
+                                                    float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16) {
+    const int64_t row = blockIdx.x;
+    const int id = idx[row];
+    for (int i = threadIdx.x; i < H; i += 256) {
+        const float v = id >= 0 ? table[(int64_t)id * H + i] : 0.f;
+        if (out_f32) out_f32[row * H + i] = v;
+        if (out_bf16) out_bf16[row * H + i] = f32_to_bf16(v);
+    }
+}
+
+// ----------------------------------------------------------------------------- codec elementwise
+__global__ void k_snake(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ a, const float* __restrict__ ib,
+                        bf16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float v = x[i];
+        const float s = __sinf(v * a[c]);
+        out[i] = f32_to_bf16(v + ib[c] * s * s);
+    }
+}
+
+// ConvNeXt front half: depthwise causal conv k=7 over time, then LayerNorm over channels -> bf16.
+// One workgroup per (b, t) row; channels-last so the 7 taps are 7 contiguous rows.
+__global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, int T, int C, const float* __restrict__ w,
+                                                   const float* __restrict__ b, const float* __restrict__ lw,
+                                                   const float* __restrict__ lb, float eps, bf16_t* __restrict__ out) {
+    extern __shared__ float row[];
+    __shared__ float sh[4];
+    const int64_t r = blockIdx.x;
+    const int t = (int)(r % T);
+    float s1 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = b[c];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int tt = t - 6 + k;
+            if (tt >= 0) v += w[k * C + c] * x[(r - 6 + k) * C + c];
+        }
+        row[c] = v;
+        s1 += v;
+    }
+    const float mean = block_sum_f32(s1, sh) / (float)C;
+    float s2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float dlt = row[c] - mean; s2 += dlt * dlt; }
+    const float var = block_sum_f32(s2, sh) / (float)C;
+    const float inv = rsqrtf(var + eps);
+    for (int c = threadIdx.x; c < C; c += 256) out[r * C + c] = f32_to_bf16((row[c] - mean) * inv * lw[c] + lb[c]);
+}
+
+__global__ __launch_bounds__(256) void k_code_embed_mean(const bf16_t* __restrict__ table, int codebook, int Q, int H,
+                                                         const int32_t* __restrict__ codes, float* __restrict__ out) {
+    const int64_t r = blockIdx.x;
+    const float inv = 1.f / (float)Q;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = 0.f;
+        for (int q = 0; q < Q; ++q) {
+            int c = codes[r * Q + q];
+            c = c < 0 ? 0 : (c >= codebook ? codebook - 1 : c);
+            v += bf16_to_f32(table[((int64_t)q * codebook + c) * H + i]);
+        }
+        out[r * H + i] = v * inv;
+    }
+}
+
+// Last conv of the decoder: C channels -> 1, k = 7, causal, then clamp(-1, 1).  One wave per output sample
+// would waste lanes at C = 96; instead each thread owns one sample and walks 7*C contiguous bf16.
+__global__ __launch_bounds__(256) void k_final_conv(const bf16_t* __restrict__ x, int T, int C, const float* __restrict__ w, float bias,
+                                                    float* __restrict__ wav, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        float acc = bias;
+        for (int k = 0; k < 7; ++k) {
+            const int tt = t - 6 + k;
+            if (tt < 0) continue;
+            const bf16_t* p = x + (i - 6 + k) * C;
+            const float* wk = w + k * C;
+            for (int c = 0; c < C; c += 8) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p + c);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc += __uint_as_float(u[j] << 16) * wk[c + 2 * j];
+                    acc += __uint_as_float(u[j] & 0xffff0000u) * wk[c + 2 * j + 1];
+                }
+            }
+        }
+        wav[i] = fminf(1.f, fmaxf(-1.f, acc));
+    }
+}
+
+__global__ void k_f32_to_bf16(const float* __restrict__ x, int64_t n, bf16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16(x[i]);
+}
+
+inline unsigned grid_for(int64_t total, int block = 256) {
+    int64_t b = (total + block - 1) / block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, int n_slabs, const float* slab_bias,
+                       const float* scale, const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
+    if (M <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_add_rmsnorm, dim3(M), dim3(256), 0, ctx->stream, x, H, slabs, n_slabs, (int64_t)M * H, slab_bias, scale, w,
+                       eps, out_bf16, out_f32);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out) {
+    const int64_t total = (int64_t)M * I;
+    if (total <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_silu_mul, dim3(grid_for(total)), dim3(256), 0, ctx->stream, slabs, n_slabs, (int64_t)M * 2 * I, I, out, total);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_reduce_slabs(rt_ctx* ctx, const float* slabs, int n_slabs, int64_t M, int N, const float* bias, int act, float* out_f32,
+                        bf16_t* out_bf16) {
+    const int64_t total = M * N;
+    if (total <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(grid_for(total)), dim3(256), 0, ctx->stream, slabs, n_slabs, total, N, bias, act, out_f32,
+                       out_bf16, total);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
+                    const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
+                    const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer) {
+    if (M <= 0) return RT_OK;
+    if (head_dim > 128 || (head_dim & 1)) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "head_dim %d unsupported (even, <= 128)", head_dim);
+    const int width = (heads + 2 * kv_heads) * head_dim;
+    hipLaunchKernelGGL(k_qkv_post, dim3(M, heads + 2 * kv_heads), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * width, heads,
+                       kv_heads, head_dim, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, q_out,
+                       kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(), kv.max_pos);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_gather_sum(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const int32_t* d_idx, int M, int H, const float* add_vec,
+                      const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16) {
+    if (M <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_gather_sum, dim3(M), dim3(256), 0, ctx->stream, d_srcs, n_src, d_idx, H, add_vec, add_rows, add_row_idx, out_f32,
+                       out_bf16);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16) {
+    if (M <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_gather_f32, dim3(M), dim3(256), 0, ctx->stream, table, H, d_idx, out_f32, out_bf16);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* a, const float* ib, bf16_t* out_bf16) {
+    const int64_t total = rows * C;
+    if (total <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_snake, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, total, C, a, ib, out_bf16);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w, const float* b, const float* ln_w,
+                     const float* ln_b, float eps, bf16_t* out_bf16) {
+    const int64_t rows = (int64_t)B * T;
+    if (rows <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_dwconv_ln, dim3((unsigned)rows), dim3(256), C * sizeof(float), ctx->stream, x, T, C, w, b, ln_w, ln_b, eps, out_bf16);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q, int H, const int32_t* codes, int64_t rows, float* out_f32) {
+    if (rows <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_code_embed_mean, dim3((unsigned)rows), dim3(256), 0, ctx->stream, table, codebook, Q, H, codes, out_f32);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_final_conv(rt_ctx* ctx, const bf16_t* x_snaked, int B, int T, int C, const float* w, float bias, float* wav) {
+    const int64_t total = (int64_t)B * T;
+    if (total <= 0) return RT_OK;
+    if (C % 8) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "final conv: channels %d not a multiple of 8", C);
+    hipLaunchKernelGGL(k_final_conv, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x_snaked, T, C, w, bias, wav, total);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out) {
+    if (n <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(n)), dim3(256), 0, ctx->stream, x, n, out);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}

@@ -1,0 +1,161 @@
+"""Kernel-level numerics on the GPU through the C ABI's test hooks: each HIP kernel against a
+plain PyTorch float32 reference of the same op (bf16 inputs are exact in float32, so the only
+differences are accumulation order and the final rounding)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rho_tts_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def gemm(ctx, a, w, taps=1, tap_stride=1, tap_offset=0, rows_out=0, rows_in=0, bias=None, act=0, mode=0, split_k=1, M=None):
+    cin = w.shape[1] // taps
+    M = M if M is not None else a.numel() // cin
+    out = torch.empty(M, w.shape[0], device="cuda")
+    torch.cuda.synchronize()
+    rc = ctx.lib.rt_debug_gemm(ctx.handle, a.data_ptr(), int(a.dtype == torch.float32), M, cin, taps, tap_stride, tap_offset,
+                               rows_out, rows_in, w.data_ptr(), w.shape[0], bias.data_ptr() if bias is not None else None, act,
+                               out.data_ptr(), mode, split_k)
+    ctx.check(rc, "rt_debug_gemm")
+    return out
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 256, 512), (1, 96, 96), (8, 3072, 2048), (33, 64, 128), (64, 160, 1024)])
+@pytest.mark.parametrize("split", [1, 2, 0])
+def test_skinny_gemm_matches_fp32(ctx, M, N, K, split):
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = rnd(N, K, scale=0.05, seed=2).to(torch.bfloat16).cuda()
+    if split and (K // 16) % split:
+        pytest.skip("split does not divide")
+    out = gemm(ctx, a, w, mode=1, split_k=split)
+    ref = a.float() @ w.float().T
+    assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+    # integer-valued operands: products and sums are exact in f32 -> bit-exact, catches any fragment-layout error
+    ai = torch.randint(-4, 5, (M, K), generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).cuda()
+    wi = torch.randint(-4, 5, (N, K), generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
+    assert torch.equal(gemm(ctx, ai, wi, mode=1, split_k=split), ai.float() @ wi.float().T)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (1000, 96, 672), (5, 40, 16), (257, 384, 2048)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_tiled_gemm_matches_fp32(ctx, M, N, K, f32):
+    a = rnd(M, K, seed=5).to(torch.bfloat16)
+    w = rnd(N, K, scale=0.05, seed=6).to(torch.bfloat16).cuda()
+    a_dev = a.float().cuda() if f32 else a.cuda()
+    bias = rnd(N, seed=7).cuda()
+    for split in (1, 3):
+        out = gemm(ctx, a_dev, w, bias=bias, mode=0, split_k=split)
+        ref = a.float().cuda() @ w.float().T + bias
+        assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+    ai = torch.randint(-4, 5, (M, K), generator=torch.Generator().manual_seed(8)).to(torch.bfloat16)
+    wi = torch.randint(-4, 5, (N, K), generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).cuda()
+    a_dev = ai.float().cuda() if f32 else ai.cuda()
+    assert torch.equal(gemm(ctx, a_dev, wi, mode=0), ai.float().cuda() @ wi.float().T)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_tiled_gemm_epilogue_activations(ctx, act):
+    a = rnd(70, 64, seed=1).to(torch.bfloat16).cuda()
+    w = rnd(48, 64, scale=0.2, seed=2).to(torch.bfloat16).cuda()
+    bias = rnd(48, seed=3).cuda()
+    ref = a.float() @ w.float().T + bias
+    ref = [ref, torch.nn.functional.silu(ref), torch.nn.functional.gelu(ref)][act]
+    assert float((gemm(ctx, a, w, bias=bias, act=act) - ref).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize("C_in,C_out,dil,T,B", [(16, 16, 1, 50, 2), (96, 96, 3, 333, 3), (32, 64, 9, 40, 1), (192, 192, 9, 700, 2)])
+def test_causal_dilated_conv_as_gemm(ctx, C_in, C_out, dil, T, B):
+    """Implicit-GEMM causal conv1d (k = 7) on channels-last activations == F.conv1d with left padding."""
+    x = rnd(B, T, C_in, seed=11).to(torch.bfloat16)
+    w = rnd(C_out, C_in, 7, scale=0.1, seed=12).to(torch.bfloat16)
+    wm = w.permute(0, 2, 1).reshape(C_out, 7 * C_in).contiguous().cuda()
+    out = gemm(ctx, x.cuda(), wm, taps=7, tap_stride=dil, tap_offset=-6 * dil, rows_out=T, rows_in=T, M=B * T)
+    ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.float().transpose(1, 2), (6 * dil, 0)), w.float(), dilation=dil)
+    assert float((out.view(B, T, C_out).cpu() - ref.transpose(1, 2)).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize("C_in,C_out,r,T,B", [(32, 16, 3, 20, 2), (64, 32, 8, 45, 3), (96, 48, 2, 7, 1)])
+def test_transposed_conv_as_gemm(ctx, C_in, C_out, r, T, B):
+    """ConvTranspose1d(k = 2r, stride r) trimmed r on both sides == 2-tap GEMM over (x[m], x[m+1])."""
+    x = rnd(B, T, C_in, seed=13).to(torch.bfloat16)
+    w = rnd(C_in, C_out, 2 * r, scale=0.1, seed=14).to(torch.bfloat16)
+    tap0 = w[:, :, r:].permute(2, 1, 0)
+    tap1 = w[:, :, :r].permute(2, 1, 0)
+    wm = torch.cat([tap0, tap1], dim=2).reshape(r * C_out, 2 * C_in).contiguous().cuda()
+    out = gemm(ctx, x.cuda(), wm, taps=2, tap_stride=1, tap_offset=0, rows_out=T - 1, rows_in=T, M=B * (T - 1))
+    y = torch.nn.functional.conv_transpose1d(x.float().transpose(1, 2), w.float(), stride=r)
+    ref = y[..., r: y.shape[-1] - r].transpose(1, 2)                      # [B, (T-1) r, C_out]
+    assert float((out.view(B, (T - 1) * r, C_out).cpu() - ref).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize("d,heads,kvh", [(128, 16, 8), (64, 4, 4), (32, 4, 1), (128, 4, 2)])
+@pytest.mark.parametrize("window", [0, 9])
+def test_attention_matches_fp32(ctx, d, heads, kvh, window):
+    slots, max_pos, M = 3, 70, 11
+    g = torch.Generator().manual_seed(21)
+    k = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    v = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    q = torch.randn(M, heads, d, generator=g).cuda()
+    slot = torch.randint(0, slots, (M,), generator=g).to(torch.int32).cuda()
+    pos = torch.randint(0, max_pos, (M,), generator=g).to(torch.int32)
+    pos[0], pos[1] = 0, max_pos - 1
+    pos = pos.cuda()
+    out = torch.empty(M, heads * d, dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.rt_debug_attention(ctx.handle, q.data_ptr(), M, heads, kvh, d, slot.data_ptr(), pos.data_ptr(), window,
+                                         k.data_ptr(), v.data_ptr(), slots, max_pos, out.data_ptr()), "rt_debug_attention")
+    rep = heads // kvh
+    for r in range(M):
+        hi = int(pos[r])
+        lo = max(0, hi - window + 1) if window else 0
+        K = k[int(slot[r]), :, lo:hi + 1].float().repeat_interleave(rep, 0)
+        V = v[int(slot[r]), :, lo:hi + 1].float().repeat_interleave(rep, 0)
+        s = torch.einsum("hd,htd->ht", q[r], K) * d ** -0.5
+        ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V).reshape(-1)
+        assert float((out[r].float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_sampler_matches_oracle_draw_for_draw(ctx):
+    from oracle.sampling import SamplingParams, draw, uniform
+    from rho_tts_amd._native_model import RtSampling
+    M, V = 24, 3072
+    g = torch.Generator().manual_seed(31)
+    logits = (torch.randn(M, V, generator=g) * 2.0)
+    logits[3, 100] = logits[3, 200] = float(logits[3].max()) + 1.0          # a tie at the top
+    logits[4, :] = 0.5                                                       # all equal
+    seen_h = torch.rand(M, V, generator=g) < 0.05
+    cases = [SamplingParams(False), SamplingParams(True, 0.9, 50, 1.0, 1.0), SamplingParams(True, 1.3, 64, 0.8, 1.05),
+             SamplingParams(True, 0.7, 1, 1.0, 1.0), SamplingParams(True, 1.0, 5, 0.3, 1.2)]
+    for ci, sp in enumerate(cases):
+        seen = seen_h.to(torch.uint8).cuda()
+        out = torch.empty(M, dtype=torch.int32, device="cuda")
+        rs = RtSampling(int(sp.do_sample), sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty)
+        lg = logits.cuda()
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.rt_debug_sample(ctx.handle, lg.data_ptr(), M, V, C.byref(rs), 789 + (5 << 32), 7, 3, 2048, 2150,
+                                          seen.data_ptr(), out.data_ptr()), "rt_debug_sample")
+        sup = np.zeros(V, bool)
+        sup[2048:] = True
+        sup[2150] = False
+        want = [draw(logits[r].numpy(), sp, uniform(789 + (5 << 32), r, 7, 3), sup, seen_h[r].numpy()) for r in range(M)]
+        got = out.cpu().tolist()
+        # a draw can legitimately differ only when u falls within float rounding of a CDF boundary: allow at most one
+        assert sum(int(a != b) for a, b in zip(got, want)) <= (1 if sp.do_sample else 0), (ci, got, want)
+        new_seen = seen.cpu().bool()
+        for r in range(M):
+            assert new_seen[r, got[r]]

@@ -1,0 +1,167 @@
+"""End-to-end GPU parity of the model path (through the C ABI) against the CPU oracle on the same
+seeded synthetic weights.  PARITY UNPINNED against the reference itself (qwen-tts is absent, see
+oracle/model.py); what is pinned here is HIP == oracle.
+
+Tolerances (stated per test): the GPU rounds activations to bf16 at every GEMM input and keeps the
+KV cache in bf16 (as the reference's bf16 model does); the oracle keeps activations in float32.
+  - teacher-forced logits: max |diff| <= 4 % of the logits' standard deviation
+  - greedy code agreement on free-running decode: >= 90 % of the codes of the first frames
+  - code2wav waveform RMSE < 1e-3 (BASELINE.json's stated bar), same codes in both
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.model import OracleModel, Voice
+from oracle.sampling import SamplingParams
+from rho_tts_amd import config, weights
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(8)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rho_tts_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def build(ctx, cfg, max_batch=8):
+    from rho_tts_amd._native_model import NativeModel
+    state = weights.synthetic_state(cfg, 789)
+    nm = NativeModel(ctx, cfg, max_batch=max_batch)
+    nm.load_state({k: v.cuda() for k, v in state.items()})
+    return nm, OracleModel(cfg, state)
+
+
+@pytest.fixture(scope="module", params=["tiny", "small"])
+def models(request, ctx):
+    cfg = config.PRESETS[request.param]()
+    nm, om = build(ctx, cfg)
+    yield cfg, nm, om
+    nm.close()
+
+
+def make_voice(cfg, clone=True, n_ref=9, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    if clone:
+        return Voice("english", speaker_embed=(torch.randn(cfg.talker.hidden, generator=g) * 0.05),
+                     ref_text_ids=[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (5,), generator=g)],
+                     ref_codes=torch.randint(0, cfg.codec.codebook_size, (n_ref, cfg.n_groups), generator=g))
+    return Voice("chinese", speaker="ryan")
+
+
+def set_voice(nm, v):
+    return nm.set_voice(v.language, v.speaker, v.speaker_embed, v.ref_text_ids, v.ref_codes)
+
+
+TEXTS = [[10, 11, 12], [20, 21, 22, 23, 24, 25, 26], [30], [40, 41, 42, 43]]
+FRAMES = [6, 5, 7, 6]
+
+
+@pytest.mark.parametrize("clone", [True, False])
+def test_teacher_forced_logits_match_oracle(models, clone):
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    v = make_voice(cfg, clone)
+    n_prefix = set_voice(nm, v)
+    assert n_prefix == om.prefix_embeddings(v).shape[0] == nm.prefix_len()
+    tr_o = {}
+    free = om.generate(v, TEXTS, FRAMES, SamplingParams(), trace=tr_o)          # oracle greedy trajectory
+    codes, tr = nm.generate(TEXTS, FRAMES, RtSampling(0, 1.0, 1, 1.0, 1.0), forced_codes=free, trace=True)
+    for a, b in zip(codes, free):
+        assert torch.equal(a, b)                                                   # forced codes come back unchanged
+    t_o = torch.stack(tr_o["talker_logits"])                                       # [T, B, V]
+    T = t_o.shape[0]
+    t_g = tr["talker"][:T].cpu()
+    valid = torch.zeros(T, len(TEXTS), dtype=torch.bool)
+    for b, n in enumerate(FRAMES):
+        valid[:n, b] = True
+    V0 = cfg.codec.codebook_size
+    err = (t_g - t_o)[valid][:, :V0].abs().max()
+    assert float(err) <= 0.04 * float(t_o[valid][:, :V0].std()), float(err)
+    p_o = torch.stack(tr_o["pred_logits"]).view(T, cfg.n_groups - 1, len(TEXTS), -1)
+    p_g = tr["predictor"][:T].cpu()
+    vp = valid[:, None, :].expand(-1, cfg.n_groups - 1, -1)
+    err = (p_g - p_o)[vp].abs().max()
+    assert float(err) <= 0.04 * float(p_o[vp].std()), float(err)
+
+
+def test_greedy_free_running_agreement(models):
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    v = make_voice(cfg, True)
+    set_voice(nm, v)
+    want = om.generate(v, TEXTS, FRAMES, SamplingParams())
+    got = nm.generate(TEXTS, FRAMES, RtSampling(0, 1.0, 1, 1.0, 1.0))
+    assert [g.shape for g in got] == [w.shape for w in want]
+    # near-ties in random-weight logits can flip an arg-max and the trajectories then diverge for good,
+    # so compare the first two frames of every item, where divergence has not compounded
+    agree = np.mean([float((g[:2] == w[:2]).float().mean()) for g, w in zip(got, want)])
+    assert agree >= 0.9, agree
+
+
+def test_sampling_is_reproducible_and_batch_invariant(models):
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    set_voice(nm, make_voice(cfg, True))
+    sp = RtSampling(1, 0.9, 50, 1.0, 1.05)
+    a = nm.generate(TEXTS, FRAMES, sp, seed=123)
+    b = nm.generate(TEXTS, FRAMES, sp, seed=123)
+    c = nm.generate(TEXTS, FRAMES, sp, seed=124)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not all(torch.equal(x, y) for x, y in zip(a, c))
+    solo = nm.generate([TEXTS[2]], [FRAMES[2]], sp, seed=123, item_ids=[2])
+    assert torch.equal(solo[0], a[2])                      # item 2 alone == item 2 inside the batch
+    for x in a:
+        assert int(x[:, 0].max()) < cfg.codec.codebook_size and int(x.min()) >= 0
+
+
+def test_eos_and_max_frames(models):
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    set_voice(nm, make_voice(cfg, False))
+    G = cfg.n_groups
+    forced = [torch.tensor([[1] * G, [2] * G, [cfg.codec_eos_id] + [0] * (G - 1)]), torch.randint(0, 60, (5, G))]
+    out = nm.generate([[1, 2], [3]], [5, 4], RtSampling(0, 1, 1, 1, 1), ignore_eos=False, forced_codes=forced)
+    assert out[0].shape[0] == 2 and out[1].shape[0] == 4
+    with pytest.raises(RuntimeError, match="length"):
+        nm.generate([[1] * 10], [cfg.max_positions], RtSampling(0, 1, 1, 1, 1))
+    with pytest.raises(ValueError):
+        nm.generate([[1]], [3], RtSampling(1, 0.9, 500, 1.0, 1.0))
+
+
+def test_voice_blob_roundtrip(models):
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    v = make_voice(cfg, True)
+    n = set_voice(nm, v)
+    ref = nm.generate(TEXTS[:2], FRAMES[:2], RtSampling(0, 1, 1, 1, 1))
+    blob = nm.export_voice().clone()
+    set_voice(nm, make_voice(cfg, False))                  # overwrite with another voice
+    other = nm.generate(TEXTS[:2], FRAMES[:2], RtSampling(0, 1, 1, 1, 1))
+    nm.import_voice(n, blob)                               # what a non-root rank does after the RCCL broadcast
+    back = nm.generate(TEXTS[:2], FRAMES[:2], RtSampling(0, 1, 1, 1, 1))
+    assert all(torch.equal(a, b) for a, b in zip(ref, back))
+    assert not all(torch.equal(a, b) for a, b in zip(ref, other))
+
+
+def test_code2wav_rmse(models):
+    cfg, nm, om = models
+    g = torch.Generator().manual_seed(9)
+    Q = cfg.codec.num_quantizers
+    lens = [7, 12, 9]
+    codes = [torch.randint(0, cfg.codec.codebook_size, (n, Q), generator=g) for n in lens]
+    wavs = nm.code2wav(codes)
+    for c, w in zip(codes, wavs):
+        ref = om.code2wav(c.T[None])[0]
+        assert w.shape[0] == ref.shape[0] == om.wav_length(c.shape[0]) == nm.wav_length(c.shape[0])
+        rmse = float(torch.sqrt(torch.mean((w.cpu() - ref) ** 2)))
+        assert rmse < 1e-3, rmse
+        assert float(ref.abs().max()) > 0.05               # the comparison is not on silence
+    # right-padding inside a ragged batch does not leak into shorter items (everything is causal up to the
+    # transposed convs' one-step look-ahead, which the length trim removes)
+    solo = nm.code2wav([codes[0]])[0]
+    assert torch.equal(solo, wavs[0])
