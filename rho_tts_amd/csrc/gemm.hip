@@ -123,9 +123,14 @@ __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B ro
     return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
 }
 
-template <bool A_F32>
+// SPLIT: the f32 A operand is fed as two bf16 planes, hi = bf16(x) and lo = bf16(x - hi), and every B fragment
+// is multiplied with both (2x MFMA work): products stay exact, activation precision goes from 2^-9 to ~2^-17.
+// Used by the codec decoder, whose waveform has to agree with the f32-activation oracle to RMSE < 1e-3.
+template <bool A_F32, bool SPLIT>
 __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * 64];
+    constexpr int PLANES = SPLIT ? 2 : 1;
+    constexpr int BUF = BM * 64 * PLANES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
     }
     const int t_limit = g.a.rows_out > 0 ? g.a.rows_in : 0x7fffffff;
 
-    auto load_piece = [&](int i, s8_t& dst) {
+    auto load_piece = [&](int i, s8_t& dst, s8_t& dst_lo) {
         const int ti = row_t[i] + p_tap[i] * g.a.tap_stride;
         const bool ok = row_ok[i] && p_tap[i] < g.a.taps && ti >= 0 && (g.a.rows_out == 0 || ti < t_limit);
         if (ok) {
@@ -172,20 +177,35 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 pk[2] = (int)pack_bf16x2(v1[0], v1[1]);
                 pk[3] = (int)pack_bf16x2(v1[2], v1[3]);
                 dst = __builtin_bit_cast(s8_t, pk);
+                if (SPLIT) {
+                    float rs[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        rs[j] = v0[j] - __uint_as_float(((unsigned)(unsigned short)dst[j]) << 16);
+                        rs[4 + j] = v1[j] - __uint_as_float(((unsigned)(unsigned short)dst[4 + j]) << 16);
+                    }
+                    i4_t pl;
+                    pl[0] = (int)pack_bf16x2(rs[0], rs[1]);
+                    pl[1] = (int)pack_bf16x2(rs[2], rs[3]);
+                    pl[2] = (int)pack_bf16x2(rs[4], rs[5]);
+                    pl[3] = (int)pack_bf16x2(rs[6], rs[7]);
+                    dst_lo = __builtin_bit_cast(s8_t, pl);
+                }
             } else {
                 dst = *reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.a.ptr) + off);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j] = 0;
+            for (int j = 0; j < 8; ++j) { dst[j] = 0; if (SPLIT) dst_lo[j] = 0; }
         }
         // advance this piece by BK along K for the next iteration
         p_ci[i] += BK;
         while (p_ci[i] >= g.a.Cin) { p_ci[i] -= g.a.Cin; ++p_tap[i]; }
     };
-    auto store_piece = [&](int i, int buf, const s8_t& v) {
+    auto store_piece = [&](int i, int buf, const s8_t& v, const s8_t& v_lo) {
         const int p = tid + i * 256;
-        *reinterpret_cast<s8_t*>(lds + buf * (BM * 64) + lds_a_off(p >> 2, p & 3)) = v;
+        *reinterpret_cast<s8_t*>(lds + buf * BUF + lds_a_off(p >> 2, p & 3)) = v;
+        if (SPLIT) *reinterpret_cast<s8_t*>(lds + buf * BUF + BM * 64 + lds_a_off(p >> 2, p & 3)) = v_lo;
     };
     // ---- B fragments straight from the packed weights (global -> VGPR), one 16-B load per (nt, kt)
     const int nt_base = (n0 >> 5) + wn * 2;
@@ -212,37 +232,42 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    s8_t ra[2], rb[2][2], rb_next[2][2];
-    load_piece(0, ra[0]);
-    load_piece(1, ra[1]);
+    s8_t ra[2], rl[2], rb[2][2], rb_next[2][2];
+    load_piece(0, ra[0], rl[0]);
+    load_piece(1, ra[1], rl[1]);
     load_b(0, rb);
-    store_piece(0, 0, ra[0]);
-    store_piece(1, 0, ra[1]);
+    store_piece(0, 0, ra[0], rl[0]);
+    store_piece(1, 0, ra[1], rl[1]);
     __syncthreads();
 
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
         const bool more = it + 1 < n_it;
         if (more) {
-            load_piece(0, ra[0]);
-            load_piece(1, ra[1]);
+            load_piece(0, ra[0], rl[0]);
+            load_piece(1, ra[1], rl[1]);
             load_b(it + 1, rb_next);
         }
-        s8_t fa[2][2];
+        s8_t fa[2][2], fl[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * (BM * 64) + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
+            for (int kk = 0; kk < 2; ++kk) {
+                fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
+                if (SPLIT) fl[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + BM * 64 + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
+            }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(fa[mt][kk], rb[nt][kk], acc[mt][nt]);
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = mfma32(fa[mt][kk], rb[nt][kk], acc[mt][nt]);
+                    if (SPLIT) acc[mt][nt] = mfma32(fl[mt][kk], rb[nt][kk], acc[mt][nt]);
+                }
         if (more) {
-            store_piece(0, buf ^ 1, ra[0]);
-            store_piece(1, buf ^ 1, ra[1]);
+            store_piece(0, buf ^ 1, ra[0], rl[0]);
+            store_piece(1, buf ^ 1, ra[1], rl[1]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 if (e.bias) bias = e.bias[n];
                 if (e.scale) scale = e.scale[n];
                 if (e.act == ACT_SNAKE) { sa = e.snake_a[n]; sib = e.snake_ib[n]; }
-                if (e.out2_bf16) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
+                if (e.out2_bf16 || e.out2_f32) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -278,12 +303,17 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 v += bias;
                 if (e.act == ACT_SILU) v = v / (1.f + __expf(-v));
                 else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                else if (e.act == ACT_SNAKE) { const float s = __sinf(v * sa); v = v + sib * s * s; }
+                else if (e.act == ACT_SNAKE) { const float s = sinf(v * sa); v = v + sib * s * s; }
                 v *= scale;
                 if (e.residual) v += e.residual[o];
                 if (e.out_f32) e.out_f32[o] = v;
                 if (e.out_bf16) e.out_bf16[o] = f32_to_bf16(v);
-                if (e.out2_bf16) { const float s = __sinf(v * s2a); e.out2_bf16[o] = f32_to_bf16(v + s2ib * s * s); }
+                if (e.out2_bf16 || e.out2_f32) {
+                    const float s = sinf(v * s2a);
+                    const float v2 = v + s2ib * s * s;
+                    if (e.out2_bf16) e.out2_bf16[o] = f32_to_bf16(v2);
+                    if (e.out2_f32) e.out2_f32[o] = v2;
+                }
             }
         }
 }
@@ -345,8 +375,10 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     const int64_t my = (a.M + BM - 1) / BM;
     if (my > 0x7fffffff) return rt_fail(ctx, RT_ERR_LENGTH, "gemm: length %lld rows too large", (long long)a.M);
     dim3 grid((unsigned)my, (w.N + BN - 1) / BN, e.split_k);
-    if (a.is_f32) hipLaunchKernelGGL(k_gemm_tiled<true>, grid, dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL(k_gemm_tiled<false>, grid, dim3(256), 0, ctx->stream, g);
+    if (a.split && !a.is_f32) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand");
+    if (a.split) hipLaunchKernelGGL((k_gemm_tiled<true, true>), grid, dim3(256), 0, ctx->stream, g);
+    else if (a.is_f32) hipLaunchKernelGGL((k_gemm_tiled<true, false>), grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_gemm_tiled<false, false>), grid, dim3(256), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

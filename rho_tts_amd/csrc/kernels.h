@@ -20,6 +20,7 @@ struct PackedW {
 struct GemmA {
     const void* ptr = nullptr;
     int is_f32 = 0;        // 1: float32 source converted to bf16 on load; 0: bf16
+    int split = 0;         // 1 (f32 source only): feed hi + lo bf16 planes, ~f32 activation precision at 2x MFMA work
     int64_t M = 0;
     int Cin = 0;           // K = taps * Cin, Cin % 8 == 0
     int taps = 1;
@@ -44,6 +45,7 @@ struct GemmEpi {
     const float* snake_a = nullptr;      // exp(alpha)
     const float* snake_ib = nullptr;     // 1 / (exp(beta) + 1e-9)
     bf16_t* out2_bf16 = nullptr;
+    float* out2_f32 = nullptr;
     const float* snake2_a = nullptr;
     const float* snake2_ib = nullptr;
     int64_t ldc = 0;
@@ -122,9 +124,9 @@ int launch_sample(rt_ctx* ctx, const SampleArgs& a);
 // -------------------------------------------------------------------------------- codec elementwise
 int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* a, const float* ib, bf16_t* out_bf16);
 int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w /*[7][C]*/, const float* b,
-                     const float* ln_w, const float* ln_b, float eps, bf16_t* out_bf16);
+                     const float* ln_w, const float* ln_b, float eps, float* out_f32);
 int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q, int H, const int32_t* codes /*[B][T][Q]*/,
                            int64_t rows, float* out_f32);
-int launch_final_conv(rt_ctx* ctx, const bf16_t* x_snaked, int B, int T, int C, const float* w /*[7][C]*/, float bias,
+int launch_final_conv(rt_ctx* ctx, const float* x_snaked, int B, int T, int C, const float* w /*[7][C]*/, float bias,
                       float* wav /*[B][T]*/);
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out);

@@ -935,7 +935,8 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         RT_TRY(alloc_stack_ws(m, c.codec_tf, (int)rows0, &w));
         RT_TRY(stack_forward(m, m->ctf, w, h, (int)rows0, d_slot, d_pos, 0, nullptr, hn));
     }
-    // ---- ConvNeXt upsampling stages (transposed conv k = stride = r is a plain GEMM in channels-last)
+    // ---- ConvNeXt upsampling stages (transposed conv k = stride = r is a plain GEMM in channels-last).
+    // Every conv-as-GEMM below runs with split (hi + lo) activations: see k_gemm_tiled.
     float* cur = hn;
     int64_t Tc = T;
     for (int i = 0; i < c.n_upsampling; ++i) {
@@ -943,30 +944,30 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         const int r = c.upsampling_ratios[i];
         float* up = nullptr;
         RT_TRY(pool_arr(m, (size_t)B * Tc * r * Hc, &up));
-        GemmA a; a.ptr = cur; a.is_f32 = 1; a.M = (int64_t)B * Tc; a.Cin = Hc;
+        GemmA a; a.ptr = cur; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = Hc;
         GemmEpi e; e.bias = VEC(m, u + ".tconv_b"); e.out_f32 = up; e.ldc = (int64_t)r * Hc;
         RT_TRY(launch_gemm(ctx, a, PW(m, u + ".tconv"), e));
         Tc *= r;
         const int64_t rows = (int64_t)B * Tc;
-        bf16_t *ln = nullptr, *mid = nullptr;
+        float *ln = nullptr, *mid = nullptr;
         RT_TRY(pool_arr(m, (size_t)rows * Hc, &ln));
         RT_TRY(pool_arr(m, (size_t)rows * 4 * Hc, &mid));
         RT_TRY(launch_dwconv_ln(ctx, up, B, (int)Tc, Hc, VEC(m, u + ".dw_w"), VEC(m, u + ".dw_b"), VEC(m, u + ".ln_w"), VEC(m, u + ".ln_b"), 1e-6f, ln));
-        GemmA a1; a1.ptr = ln; a1.M = rows; a1.Cin = Hc;
-        GemmEpi e1; e1.bias = VEC(m, u + ".pw1_b"); e1.act = ACT_GELU; e1.out_bf16 = mid; e1.ldc = 4 * (int64_t)Hc;
+        GemmA a1; a1.ptr = ln; a1.is_f32 = 1; a1.split = 1; a1.M = rows; a1.Cin = Hc;
+        GemmEpi e1; e1.bias = VEC(m, u + ".pw1_b"); e1.act = ACT_GELU; e1.out_f32 = mid; e1.ldc = 4 * (int64_t)Hc;
         RT_TRY(launch_gemm(ctx, a1, PW(m, u + ".pw1"), e1));
-        GemmA a2; a2.ptr = mid; a2.M = rows; a2.Cin = 4 * Hc;
+        GemmA a2; a2.ptr = mid; a2.is_f32 = 1; a2.split = 1; a2.M = rows; a2.Cin = 4 * Hc;
         GemmEpi e2; e2.bias = VEC(m, u + ".pw2_b"); e2.scale = VEC(m, u + ".gamma"); e2.residual = up; e2.out_f32 = up; e2.ldc = Hc;
         RT_TRY(launch_gemm(ctx, a2, PW(m, u + ".pw2"), e2));
         cur = up;
     }
     // ---- decoder: conv k7 -> [SnakeBeta, transposed conv, 3 residual units] x n -> SnakeBeta -> conv k7 -> clamp
-    bf16_t* s_in = nullptr;  // snake-activated input of the next transposed conv
+    float* s_in = nullptr;  // snake-activated input of the next transposed conv
     {
         RT_TRY(pool_arr(m, (size_t)B * Tc * m->dec_ch[0], &s_in));
-        GemmA a; a.ptr = cur; a.is_f32 = 1; a.M = (int64_t)B * Tc; a.Cin = Hc; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
+        GemmA a; a.ptr = cur; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = Hc; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
         a.rows_out = (int)Tc; a.rows_in = (int)Tc;
-        GemmEpi e; e.bias = VEC(m, "codec.dec0_b"); e.out2_bf16 = s_in; e.snake2_a = VEC(m, "codec.b0.sa"); e.snake2_ib = VEC(m, "codec.b0.sib");
+        GemmEpi e; e.bias = VEC(m, "codec.dec0_b"); e.out2_f32 = s_in; e.snake2_a = VEC(m, "codec.b0.sa"); e.snake2_ib = VEC(m, "codec.b0.sib");
         e.ldc = m->dec_ch[0];
         RT_TRY(launch_gemm(ctx, a, PW(m, "codec.dec0"), e));
     }
@@ -976,30 +977,29 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         const int64_t To = (Tc - 1) * r;
         if (To < 1) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: length collapsed in decoder block %d", i);
         const int64_t rows = (int64_t)B * To;
-        float* xr = nullptr;
-        bf16_t *s1 = nullptr, *s2 = nullptr;
+        float *xr = nullptr, *s1 = nullptr, *s2 = nullptr;
         RT_TRY(pool_arr(m, (size_t)rows * cout, &xr));
         RT_TRY(pool_arr(m, (size_t)rows * cout, &s1));
         RT_TRY(pool_arr(m, (size_t)rows * cout, &s2));
         {
             // transposed conv k = 2r, stride r, r samples trimmed on both sides: out[m*r + j] = x[m+1] W[j] + x[m] W[j + r]
-            GemmA a; a.ptr = s_in; a.M = (int64_t)B * (Tc - 1); a.Cin = cin; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
+            GemmA a; a.ptr = s_in; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * (Tc - 1); a.Cin = cin; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
             a.rows_out = (int)(Tc - 1); a.rows_in = (int)Tc;
-            float *a1x = m->xvec[bn + ".u0.a1"], *ib1x = m->xvec[bn + ".u0.ib1"];
-            GemmEpi e; e.bias = VEC(m, bn + ".tconv_b"); e.out_f32 = xr; e.out2_bf16 = s1; e.snake2_a = a1x; e.snake2_ib = ib1x;
+            GemmEpi e; e.bias = VEC(m, bn + ".tconv_b"); e.out_f32 = xr; e.out2_f32 = s1;
+            e.snake2_a = m->xvec[bn + ".u0.a1"]; e.snake2_ib = m->xvec[bn + ".u0.ib1"];
             e.ldc = (int64_t)r * cout;
             RT_TRY(launch_gemm(ctx, a, PW(m, bn + ".tconv"), e));
         }
         for (int j = 0; j < 3; ++j) {
             const std::string u = bn + ".u" + std::to_string(j);
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            GemmA a; a.ptr = s1; a.M = rows; a.Cin = cout; a.taps = 7; a.tap_stride = dil; a.tap_offset = -6 * dil;
+            GemmA a; a.ptr = s1; a.is_f32 = 1; a.split = 1; a.M = rows; a.Cin = cout; a.taps = 7; a.tap_stride = dil; a.tap_offset = -6 * dil;
             a.rows_out = (int)To; a.rows_in = (int)To;
             GemmEpi e; e.bias = VEC(m, u + ".c1_b"); e.act = ACT_SNAKE; e.snake_a = VEC(m, u + ".a2"); e.snake_ib = VEC(m, u + ".ib2");
-            e.out_bf16 = s2; e.ldc = cout;
+            e.out_f32 = s2; e.ldc = cout;
             RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e));
-            GemmA a2; a2.ptr = s2; a2.M = rows; a2.Cin = cout;
-            GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_bf16 = s1; e2.ldc = cout;
+            GemmA a2; a2.ptr = s2; a2.is_f32 = 1; a2.split = 1; a2.M = rows; a2.Cin = cout;
+            GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_f32 = s1; e2.ldc = cout;
             if (j < 2) { e2.snake2_a = VEC(m, bn + ".u" + std::to_string(j + 1) + ".a1"); e2.snake2_ib = VEC(m, bn + ".u" + std::to_string(j + 1) + ".ib1"); }
             else if (i + 1 < c.n_upsample_rates) { e2.snake2_a = VEC(m, "codec.b" + std::to_string(i + 1) + ".sa"); e2.snake2_ib = VEC(m, "codec.b" + std::to_string(i + 1) + ".sib"); }
             else { e2.snake2_a = VEC(m, "codec.fin_a"); e2.snake2_ib = VEC(m, "codec.fin_ib"); }

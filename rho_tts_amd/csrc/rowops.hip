@@ -169,7 +169,7 @@ __global__ void k_snake(const float* __restrict__ x, int64_t total, int C, const
 // One workgroup per (b, t) row; channels-last so the 7 taps are 7 contiguous rows.
 __global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, int T, int C, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ lw,
-                                                   const float* __restrict__ lb, float eps, bf16_t* __restrict__ out) {
+                                                   const float* __restrict__ lb, float eps, float* __restrict__ out) {
     extern __shared__ float row[];
     __shared__ float sh[4];
     const int64_t r = blockIdx.x;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, 
     for (int c = threadIdx.x; c < C; c += 256) { const float dlt = row[c] - mean; s2 += dlt * dlt; }
     const float var = block_sum_f32(s2, sh) / (float)C;
     const float inv = rsqrtf(var + eps);
-    for (int c = threadIdx.x; c < C; c += 256) out[r * C + c] = f32_to_bf16((row[c] - mean) * inv * lw[c] + lb[c]);
+    for (int c = threadIdx.x; c < C; c += 256) out[r * C + c] = (row[c] - mean) * inv * lw[c] + lb[c];
 }
 
 __global__ __launch_bounds__(256) void k_code_embed_mean(const bf16_t* __restrict__ table, int codebook, int Q, int H,
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_code_embed_mean(const bf16_t* __restric
 
 // Last conv of the decoder: C channels -> 1, k = 7, causal, then clamp(-1, 1).  One wave per output sample
 // would waste lanes at C = 96; instead each thread owns one sample and walks 7*C contiguous bf16.
-__global__ __launch_bounds__(256) void k_final_conv(const bf16_t* __restrict__ x, int T, int C, const float* __restrict__ w, float bias,
+__global__ __launch_bounds__(256) void k_final_conv(const float* __restrict__ x, int T, int C, const float* __restrict__ w, float bias,
                                                     float* __restrict__ wav, int64_t total) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % T);
@@ -218,16 +218,11 @@ __global__ __launch_bounds__(256) void k_final_conv(const bf16_t* __restrict__ x
         for (int k = 0; k < 7; ++k) {
             const int tt = t - 6 + k;
             if (tt < 0) continue;
-            const bf16_t* p = x + (i - 6 + k) * C;
+            const float* p = x + (i - 6 + k) * C;
             const float* wk = w + k * C;
-            for (int c = 0; c < C; c += 8) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p + c);
-                const unsigned u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc += __uint_as_float(u[j] << 16) * wk[c + 2 * j];
-                    acc += __uint_as_float(u[j] & 0xffff0000u) * wk[c + 2 * j + 1];
-                }
+            for (int c = 0; c < C; c += 4) {
+                const f4_t v = *reinterpret_cast<const f4_t*>(p + c);
+                acc += v[0] * wk[c] + v[1] * wk[c + 1] + v[2] * wk[c + 2] + v[3] * wk[c + 3];
             }
         }
         wav[i] = fminf(1.f, fmaxf(-1.f, acc));
@@ -313,10 +308,10 @@ int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* 
 }
 
 int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w, const float* b, const float* ln_w,
-                     const float* ln_b, float eps, bf16_t* out_bf16) {
+                     const float* ln_b, float eps, float* out_f32) {
     const int64_t rows = (int64_t)B * T;
     if (rows <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_dwconv_ln, dim3((unsigned)rows), dim3(256), C * sizeof(float), ctx->stream, x, T, C, w, b, ln_w, ln_b, eps, out_bf16);
+    hipLaunchKernelGGL(k_dwconv_ln, dim3((unsigned)rows), dim3(256), C * sizeof(float), ctx->stream, x, T, C, w, b, ln_w, ln_b, eps, out_f32);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -328,7 +323,7 @@ int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q
     return RT_OK;
 }
 
-int launch_final_conv(rt_ctx* ctx, const bf16_t* x_snaked, int B, int T, int C, const float* w, float bias, float* wav) {
+int launch_final_conv(rt_ctx* ctx, const float* x_snaked, int B, int T, int C, const float* w, float bias, float* wav) {
     const int64_t total = (int64_t)B * T;
     if (total <= 0) return RT_OK;
     if (C % 8) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "final conv: channels %d not a multiple of 8", C);

@@ -104,7 +104,7 @@ def tensor_specs(cfg: ModelConfig) -> List[Spec]:
                   (f"{u}.conv2.conv.weight", (cout, cout, 1), "fan", 0.6), (f"{u}.conv2.conv.bias", (cout,), "bias", 0.01)]
     n = len(c.upsample_rates) + 1
     s += [(f"codec.decoder.{n}.alpha", (ch[-1],), "bias", 0.3), (f"codec.decoder.{n}.beta", (ch[-1],), "bias", 0.3),
-          (f"codec.decoder.{n + 1}.conv.weight", (1, ch[-1], 7), "fan", 0.25), (f"codec.decoder.{n + 1}.conv.bias", (1,), "bias", 0.0)]
+          (f"codec.decoder.{n + 1}.conv.weight", (1, ch[-1], 7), "fan", 0.1), (f"codec.decoder.{n + 1}.conv.bias", (1,), "bias", 0.0)]
     return s
 
 

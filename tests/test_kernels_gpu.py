@@ -18,12 +18,13 @@ def ctx():
     c.close()
 
 
-def gemm(ctx, a, w, taps=1, tap_stride=1, tap_offset=0, rows_out=0, rows_in=0, bias=None, act=0, mode=0, split_k=1, M=None):
+def gemm(ctx, a, w, taps=1, tap_stride=1, tap_offset=0, rows_out=0, rows_in=0, bias=None, act=0, mode=0, split_k=1, M=None,
+         split_prec=False):
     cin = w.shape[1] // taps
     M = M if M is not None else a.numel() // cin
     out = torch.empty(M, w.shape[0], device="cuda")
     torch.cuda.synchronize()
-    rc = ctx.lib.rt_debug_gemm(ctx.handle, a.data_ptr(), int(a.dtype == torch.float32), M, cin, taps, tap_stride, tap_offset,
+    rc = ctx.lib.rt_debug_gemm(ctx.handle, a.data_ptr(), (2 if split_prec else 1) if a.dtype == torch.float32 else 0, M, cin, taps, tap_stride, tap_offset,
                                rows_out, rows_in, w.data_ptr(), w.shape[0], bias.data_ptr() if bias is not None else None, act,
                                out.data_ptr(), mode, split_k)
     ctx.check(rc, "rt_debug_gemm")
@@ -66,6 +67,24 @@ def test_tiled_gemm_matches_fp32(ctx, M, N, K, f32):
     wi = torch.randint(-4, 5, (N, K), generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).cuda()
     a_dev = ai.float().cuda() if f32 else ai.cuda()
     assert torch.equal(gemm(ctx, a_dev, wi, mode=0), ai.float().cuda() @ wi.float().T)
+
+
+def test_split_precision_gemm_is_f32_faithful(ctx):
+    """hi + lo bf16 planes of an f32 activation: error vs the float64 product drops ~100x below plain bf16 feeding."""
+    a = rnd(300, 672, seed=41).cuda()                                     # full-precision f32 activations
+    w = rnd(96, 672, scale=0.05, seed=42).to(torch.bfloat16).cuda()
+    ref = (a.double() @ w.double().T)
+    e_plain = float((gemm(ctx, a, w).double() - ref).abs().max())
+    e_split = float((gemm(ctx, a, w, split_prec=True).double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert e_split < 2e-5 * scale and e_split * 30 < e_plain, (e_split, e_plain, scale)
+    # causal dilated conv in split mode
+    x = rnd(2, 100, 32, seed=43)
+    wc = rnd(48, 32, 7, scale=0.1, seed=44).to(torch.bfloat16)
+    wm = wc.permute(0, 2, 1).reshape(48, 7 * 32).contiguous().cuda()
+    out = gemm(ctx, x.cuda(), wm, taps=7, tap_stride=3, tap_offset=-18, rows_out=100, rows_in=100, M=200, split_prec=True)
+    refc = torch.nn.functional.conv1d(torch.nn.functional.pad(x.double().transpose(1, 2), (18, 0)), wc.double(), dilation=3)
+    assert float((out.view(2, 100, 48).cpu().double() - refc.transpose(1, 2)).abs().max()) < 2e-5 * float(refc.abs().max())
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
