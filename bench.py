@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds per wall-second of the batched generation hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+Qwen3-TTS-1.7B-shaped model, bf16 weights, batch 32 per GPU, 30-s reference-audio clone,
+10-word sentences (fixed 44 frames each: synthetic weights never emit EOS — SURVEY.md 8d).
+One step = one pass of the hot path over one batch, everything `_run_pipeline` does after the
+host-side text handling: voice-prefix prefill (conditioning) -> batched autoregressive decode
+-> codec decoder -> fused post-processing -> waveforms on the host.  Inputs (weights, reference
+conditioning arrays, token ids) are resident before the timed region.  Data is synthetic and
+weights are seeded random of the named architecture (no checkpoints offline).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank
+decodes its own 32 texts; rank 0 computes the voice prefix and broadcasts its KV blob, and the
+finished waveforms are gathered to rank 0, both inside the timed step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORDS = ("time year people way day man thing woman life child world school state family student group country problem hand "
+         "part place case week company system program question work government number night point home water room mother area "
+         "money story fact month lot right study book eye job word business issue side kind head house service friend father "
+         "power hour game line end member law car city community name president team minute idea kid body information back "
+         "parent face others level office door health person art war history party result change morning reason research girl "
+         "guy moment air teacher force education").split()
+
+
+def sentences(n: int, n_words, seed: int):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        k = n_words if isinstance(n_words, int) else int(rng.integers(n_words[0], n_words[1] + 1))
+        out.append(" ".join(WORDS[int(j)] for j in rng.integers(0, len(WORDS), k)).capitalize() + ".")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="1.7b", help="config preset: 1.7b | 0.6b | small | tiny")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--words", type=int, default=10)
+    ap.add_argument("--ref-seconds", type=float, default=30.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--greedy", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        dist = dist_mod
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from rho_tts_amd import _native, config
+    from rho_tts_amd.engine import Engine
+    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    from rho_tts_amd.dist import broadcast_voice, gather_waveforms
+
+    cfg = config.PRESETS[args.model]()
+    eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=local_rank, max_batch=args.batch)
+    if args.greedy:
+        eng.params.do_sample = False
+    B = args.batch
+    texts = sentences(B, args.words, seed=789 + rank)
+    item_ids = list(range(rank * B, (rank + 1) * B))
+    ref_words = 75 if args.ref_seconds >= 10 else max(3, int(args.ref_seconds * 2.5))
+    clip = synthetic_reference_clip(args.ref_seconds, cfg.sample_rate, 789)
+    ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(ref_words))
+    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(ref_text), "english", max_frames=eng.model.max_positions // 2)
+    post = _native.make_post_params(sample_rate=cfg.sample_rate, stages=_native.POST_PIPELINE)
+
+    def step():
+        if dist is None or rank == 0:
+            eng.set_voice(cond)                                   # conditioning: voice-prefix prefill, once per step
+        if dist is not None:
+            broadcast_voice(eng, dist, src=0)
+        raw = eng.synthesize(texts, seed=789, item_ids=item_ids)
+        outs, stats = eng.post_process([[w] for w in raw], post)
+        audio_s = sum(w.numel() for w in raw) / cfg.sample_rate
+        if dist is not None:
+            host = gather_waveforms(outs, dist, dst=0, device=dev)
+        else:
+            host = [o.cpu() for o in outs]
+        return audio_s, host
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.ctx.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    audio_local = 0.0
+    for _ in range(args.steps):
+        a, _host = step()
+        audio_local += a
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, audio_local], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, audio_total = float(tmax[0]), float(tsum[1])
+    else:
+        audio_total = audio_local
+
+    # ---- roofline of the dominant kernel (weight-streaming skinny GEMM), HIP events on the library's stream
+    roof = None
+    extra = {}
+    if not args.no_roofline:
+        eng.model.profile(True)
+        step()
+        n_l, ms, by = eng.model.profile_read()
+        eng.model.profile(False)
+        if n_l > 0 and ms > 0:
+            achieved = by / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_gemm_skinny", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": None, "launches": int(n_l),
+                    "avg_launch_us": round(ms * 1e3 / n_l, 3), "avg_bytes_per_launch": round(by / n_l, 1)}
+        # decode-step view: algorithmic bytes per frame for the local batch
+        t_, p_ = cfg.talker, cfg.predictor
+        w_talker = 2 * (t_.weight_params() + t_.hidden * cfg.codec_vocab)
+        w_pred = 2 * (p_.weight_params() + (cfg.n_groups - 1) * p_.hidden * cfg.predictor_vocab
+                      + (t_.hidden * p_.hidden if cfg.has_mtp_proj else 0))
+        frames = eng.frames_for(texts[0], 0)
+        ctx_len = eng.model.prefix_len() + args.words + 3 + frames // 2
+        kv = B * ctx_len * t_.layers * 2 * t_.kv_heads * t_.head_dim * 2
+        extra = {"bytes_per_frame": int(w_talker + w_pred + kv), "frames_per_item": frames, "prefix_rows": eng.model.prefix_len()}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args, eng)
+
+    if rank == 0:
+        line = {
+            "metric": "audio-sec/wall-sec (RTF) Qwen3-TTS-1.7B batch=32",
+            "value": round(audio_total / dt, 2),
+            "unit": "audio-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name} bf16, batch {B}/GPU, {args.ref_seconds:g}-s reference clone, {args.words}-word sentences "
+                                   f"({eng.frames_for(texts[0], 0)} frames each), sampling={'greedy' if args.greedy else 'top-k 50 T 0.9'}, "
+                                   "seeded synthetic weights", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def cpu_baseline(cfg, args, eng):
+    """The CPU oracle (oracle/model.py, a port — the reference's own CPU path needs the absent qwen-tts package) timed on
+    this box's host cores on a bounded sample of the same workload: same model shape and batch, 2-s reference clip, 4 decoded
+    frames + their codec decode + post-processing.  Reported beside the GPU number, never as the target."""
+    from oracle import postprocess as OP
+    from oracle.model import OracleModel, Voice
+    from oracle.sampling import SamplingParams
+    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    from rho_tts_amd.weights import synthetic_state
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    state = {k: v.cpu() for k, v in synthetic_state(cfg, 789, device=eng.device).items()}
+    om = OracleModel(cfg, state)
+    del state
+    B = args.batch if cfg.talker.hidden <= 1024 else min(args.batch, 32)
+    frames = 4
+    texts = sentences(B, args.words, seed=789)
+    clip = synthetic_reference_clip(2.0, cfg.sample_rate, 789)
+    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode("time year people way day"), "english")
+    v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
+    ids = [eng.tokenizer.encode(t) for t in texts]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        codes = om.generate(v, ids, [frames] * B, SamplingParams(True, 0.9, 50, 1.0, 1.05), seed=789)
+        q = cfg.codec.num_quantizers
+        wav = om.code2wav(torch.stack([c[:, :q].T for c in codes]))
+        p = OP.PostParams(sample_rate=cfg.sample_rate)
+        for b in range(B):
+            OP.finish_item([wav[b]], p)
+    dt = time.perf_counter() - t0
+    audio_s = B * wav.shape[1] / cfg.sample_rate
+    return {"value": round(audio_s / dt, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/model.py (PyTorch eager f32 on bf16-valued weights), {cfg.name}, batch {B}, 2-s reference clip, "
+                      f"{frames} frames/item decoded + codec decode + post-processing, {dt:.1f} s of CPU work"}
+
+
+if __name__ == "__main__":
+    main()

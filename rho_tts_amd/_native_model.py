@@ -370,7 +370,7 @@ class NativeModel:
             a.h_forced_offsets = (C.c_int32 * (B + 1))(*fo)
             keep.append(fa)
         if cancel_flag is not None:
-            a.h_cancel_flag = C.cast(cancel_flag, C.POINTER(C.c_int32))
+            a.h_cancel_flag = C.pointer(cancel_flag)          # a ctypes.c_int32 another thread may set to 1
         tot = sum(int(v) for v in max_frames)
         codes = (C.c_int32 * (tot * G))()
         nfr = (C.c_int32 * B)()

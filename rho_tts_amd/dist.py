@@ -1,0 +1,94 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The path shards by independent units — every text (indeed every segment) is generated independently
+(base_tts.py:726-954 keeps no cross-item state) — so there is no data-path collective in the decode.
+Exactly two collectives exist:
+  * broadcast of the voice conditioning (the prefix KV blob, tens of MB, once per voice)
+  * gather of the finished 24 kHz waveforms to rank 0 (96 KB per audio-second)
+The reference has no distributed code at all; nothing here translates an NCCL call pattern.
+All functions also run on the gloo backend with CPU tensors, which is how the CPU tests cover them.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+def shard_items(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Length-balanced deal: sort by estimated cost (descending) and give each item to the least-loaded rank.
+    Returns the item indices of every rank, each list in ascending original order."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], len(out[k]), k))
+        out[r].append(i)
+        load[r] += costs[i]
+    return [sorted(x) for x in out]
+
+
+def broadcast_voice(engine, dist, src: int = 0) -> None:
+    """Rank ``src`` has computed the voice prefix (Engine.set_voice); every other rank imports its KV blob."""
+    rank = dist.get_rank()
+    dev = engine.device
+    meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == src:
+        blob = engine.model.export_voice()
+        meta[0], meta[1] = engine.model.prefix_len(), blob.numel()
+    dist.broadcast(meta, src=src)
+    if rank != src:
+        blob = torch.empty(int(meta[1]), dtype=torch.bfloat16, device=dev)
+    dist.broadcast(blob, src=src)
+    if rank != src:
+        engine.model.import_voice(int(meta[0]), blob)
+
+
+def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=None) -> Optional[List[List[torch.Tensor]]]:
+    """Variable-length gather: returns on ``dst`` a list (per rank) of lists of CPU float32 waveforms, else None.
+    One length exchange plus one padded payload gather; ``None`` items travel as length -1."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or (wavs[0].device if len(wavs) and wavs[0] is not None else torch.device("cpu"))
+    lens = torch.tensor([(-1 if w is None else int(w.numel())) for w in wavs], dtype=torch.int64, device=device)
+    n_local = torch.tensor([lens.numel()], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    max_items = int(max(int(c) for c in counts))
+    lens_pad = torch.full((max_items,), -1, dtype=torch.int64, device=device)
+    lens_pad[: lens.numel()] = lens
+    all_lens = [torch.empty_like(lens_pad) for _ in range(world)]
+    dist.all_gather(all_lens, lens_pad)
+    totals = [int(l.clamp(min=0).sum()) for l in all_lens]
+    cap = max(1, max(totals))
+    payload = torch.zeros(cap, dtype=torch.float32, device=device)
+    off = 0
+    for w in wavs:
+        if w is not None and w.numel():
+            payload[off: off + w.numel()] = w.reshape(-1).to(device=device, dtype=torch.float32)
+            off += w.numel()
+    if rank == dst:
+        bufs = [torch.empty(cap, dtype=torch.float32, device=device) for _ in range(world)]
+        dist.gather(payload, gather_list=bufs, dst=dst)
+        out: List[List[torch.Tensor]] = []
+        for r in range(world):
+            host = bufs[r][: totals[r]].cpu()
+            items, o = [], 0
+            for n in all_lens[r].tolist()[: int(counts[r])]:
+                if n < 0:
+                    items.append(None)
+                else:
+                    items.append(host[o: o + n].clone())
+                    o += n
+            out.append(items)
+        return out
+    dist.gather(payload, gather_list=None, dst=dst)
+    return None
+
+
+def unshard(per_rank: Sequence[Sequence], shards: Sequence[Sequence[int]], n_total: int) -> List:
+    """Inverse of ``shard_items``: place rank r's k-th result at original index shards[r][k]."""
+    out = [None] * n_total
+    for r, idxs in enumerate(shards):
+        for k, i in enumerate(idxs):
+            out[i] = per_rank[r][k]
+    return out

@@ -1,0 +1,154 @@
+"""Host-side engine: one model on one GPU, batched text -> waveform.
+
+This is the piece the provider and ``bench.py`` share.  Everything numeric
+happens behind the C ABI (``librho_tts_amd.so``); this file only tokenises,
+sizes batches, and moves pointers.  No CPU fallback exists: constructing an
+Engine without a gfx950 GPU raises ``NativeUnavailable``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native_model import NativeModel, RtSampling
+from .config import ModelConfig, resolve
+from .tokenizer import load_tokenizer
+from .voice import VoiceConditioning, conditioning_from_audio, load_audio
+from .weights import load_safetensors, synthetic_state
+
+FRAME_SECONDS_PER_WORD = 0.35   # synthetic weights never emit EOS, so length is fixed by policy
+
+
+@dataclass
+class GenerationParams:
+    do_sample: bool = True
+    temperature: float = 0.9
+    top_k: int = 50
+    top_p: float = 1.0
+    repetition_penalty: float = 1.05
+    predictor_do_sample: Optional[bool] = None
+    predictor_temperature: float = 0.9
+    predictor_top_k: int = 50
+    predictor_top_p: float = 1.0
+    max_seconds: float = 60.0
+
+    def talker(self) -> RtSampling:
+        return RtSampling(int(self.do_sample), self.temperature, self.top_k, self.top_p, self.repetition_penalty)
+
+    def predictor(self) -> RtSampling:
+        ds = self.do_sample if self.predictor_do_sample is None else self.predictor_do_sample
+        return RtSampling(int(ds), self.predictor_temperature, self.predictor_top_k, self.predictor_top_p, 1.0)
+
+
+class Engine:
+    def __init__(self, model_path: str = "Qwen/Qwen3-TTS-12Hz-1.7B-Base", device_ordinal: int = 0, max_batch: int = 32,
+                 weight_seed: int = 789, cfg: Optional[ModelConfig] = None, max_positions: Optional[int] = None):
+        self.cfg = cfg or resolve(model_path)
+        self.model_path = model_path
+        self.device_ordinal = device_ordinal
+        self.device = torch.device(f"cuda:{device_ordinal}")
+        self.ctx = _native.Context(device_ordinal)          # raises NativeUnavailable without a gfx950 GPU
+        self.max_batch = max_batch
+        self.model = NativeModel(self.ctx, self.cfg, max_batch=max_batch, max_positions=max_positions)
+        has_ckpt = os.path.isdir(model_path) and any(f.endswith(".safetensors") for f in os.listdir(model_path))
+        self.synthetic = not has_ckpt
+        with torch.cuda.device(self.device):
+            if has_ckpt:
+                state = load_safetensors(self.cfg, model_path, device=self.device)
+            else:
+                state = synthetic_state(self.cfg, weight_seed, device=self.device)
+            self.model.load_state(state)
+            del state
+            torch.cuda.empty_cache()
+        self.tokenizer = load_tokenizer(model_path, self.cfg.text_vocab)
+        self.voice: Optional[VoiceConditioning] = None
+        self.params = GenerationParams()
+
+    def close(self) -> None:
+        if getattr(self, "model", None) is not None:
+            self.model.close()
+            self.model = None
+        if getattr(self, "ctx", None) is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    # ------------------------------------------------------------------ voice
+    def set_voice(self, v: VoiceConditioning) -> int:
+        self.voice = v
+        return self.model.set_voice(v.language, v.speaker, v.speaker_embed, v.ref_text_ids, v.ref_codes)
+
+    def set_voice_from_audio(self, audio_or_path, ref_text: str, language: str = "english") -> int:
+        audio = load_audio(audio_or_path, self.cfg.sample_rate) if isinstance(audio_or_path, str) else np.asarray(audio_or_path, np.float32)
+        room = self.model.max_positions // 2
+        v = conditioning_from_audio(self.cfg, audio, self.tokenizer.encode(ref_text), language, max_frames=room)
+        return self.set_voice(v)
+
+    def set_builtin_voice(self, speaker: str, language: str = "english") -> int:
+        return self.set_voice(VoiceConditioning(language, speaker, None, [], None))
+
+    # ------------------------------------------------------------------ sizing
+    def frames_for(self, text: str, n_tokens: int) -> int:
+        cap = int(self.params.max_seconds * self.cfg.frame_rate)
+        if self.synthetic:
+            n_words = max(1, len(text.split()))
+            return max(2, min(cap, int(round(self.cfg.frame_rate * FRAME_SECONDS_PER_WORD * n_words))))
+        return max(2, min(cap, 8 + 6 * n_tokens))            # eos-terminated; generous cap of ~0.5 s per token
+
+    # ------------------------------------------------------------------ generate
+    def generate_codes(self, texts: Sequence[str], seed: int, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
+                       max_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        if self.voice is None:
+            raise ValueError("no voice set: reference audio (Base models) or a built-in speaker (CustomVoice) is required")
+        ids = [self.tokenizer.encode(t) for t in texts]
+        frames = list(max_frames) if max_frames is not None else [self.frames_for(t, len(i)) for t, i in zip(texts, ids)]
+        limit = self.model.max_positions - self.model.prefix_len() - 4
+        for i, f in zip(ids, frames):
+            if len(i) + 2 + f > limit:
+                raise RuntimeError(f"length: text of {len(i)} tokens + {f} frames exceeds the {limit} free KV rows")
+        return self.model.generate(ids, frames, self.params.talker(), self.params.predictor(), seed=seed, item_ids=item_ids,
+                                   ignore_eos=self.synthetic, cancel_flag=cancel_flag)
+
+    def vocode(self, codes: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """Codec decoder with the reference architecture's chunking (chunk_frames + left_context_frames)."""
+        c = self.cfg.codec
+        out: List[Optional[torch.Tensor]] = [None] * len(codes)
+        short = [i for i, x in enumerate(codes) if 0 < x.shape[0] <= c.chunk_frames]
+        for i0 in range(0, len(short), self.max_batch):
+            grp = short[i0:i0 + self.max_batch]
+            for i, w in zip(grp, self.model.code2wav([codes[i] for i in grp])):
+                out[i] = w
+        for i, x in enumerate(codes):
+            if x.shape[0] == 0:
+                out[i] = torch.zeros(0, device=self.device)
+            elif x.shape[0] > c.chunk_frames:
+                parts, start = [], 0
+                while start < x.shape[0]:
+                    end = min(start + c.chunk_frames, x.shape[0])
+                    ctx = c.left_context_frames if start - c.left_context_frames > 0 else start
+                    w = self.model.code2wav([x[start - ctx:end]])[0]
+                    parts.append(w[ctx * c.total_upsample:])
+                    start = end
+                out[i] = torch.cat(parts)
+        return out  # type: ignore[return-value]
+
+    def synthesize(self, texts: Sequence[str], seed: int = 789, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
+                   max_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """Raw waveforms (GPU float32, 1-D) for a batch of texts, ``max_batch`` at a time."""
+        wavs: List[torch.Tensor] = []
+        for i0 in range(0, len(texts), self.max_batch):
+            sl = slice(i0, i0 + self.max_batch)
+            ids = list(item_ids[sl]) if item_ids is not None else list(range(i0, min(i0 + self.max_batch, len(texts))))
+            codes = self.generate_codes(texts[sl], seed, ids, cancel_flag, max_frames[sl] if max_frames is not None else None)
+            wavs += self.vocode(codes)
+        return wavs
+
+    # ------------------------------------------------------------------ post
+    def post_process(self, items: Sequence[Sequence[torch.Tensor]], params: _native.PostParams):
+        return self.ctx.post_process(params, items)

@@ -1,0 +1,415 @@
+"""``MI355XQwenTTS`` — the drop-in generation provider.
+
+Registers through ``TTSFactory.register_provider()`` (factory.py:110-123) and implements the two
+abstract members of ``BaseTTS`` (``_generate_audio`` base_tts.py:587-599, ``sample_rate`` :1192-1196)
+with the constructor surface of the reference's ``QwenTTS`` (providers/qwen.py:48-66).
+
+What differs from the reference, on purpose:
+  * ``batch_size`` is live.  The reference stores it and never reads it (qwen.py:59,83) and its
+    ``_run_pipeline`` is strictly sequential (base_tts.py:726,753,770).  Here ``_run_pipeline`` is
+    overridden to flatten texts -> segments, run them ``batch_size`` at a time through
+    ``_generate_audio(list)``, and finish every item (join -> loudness -> decay check) in ONE fused
+    HIP launch — with the reference's per-item semantics (listed at ``BatchedPipeline``).
+  * the voice conditioning is computed once per voice, not on every call (qwen.py:253-258).
+  * ``sample_rate`` is a constant; the reference generates a throw-away sample to learn it (qwen.py:408-413).
+  * every numeric leaf runs on the GPU through the C ABI; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import threading
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _native
+from .api import (BaseTTS, CancellationToken, CancelledException, ProviderInfo, TTSFactory, VoiceInfo)
+
+logger = logging.getLogger("rho_tts_amd")
+
+PROVIDER_NAME = "qwen_mi355x"
+BUILTIN_VOICES = ["Chelsie", "Aidan", "Vivian", "Ryan", "Aria", "Ethan", "Luna", "Harper", "James"]
+
+
+class BatchedPipeline:
+    """Batched restatement of ``BaseTTS._run_pipeline`` (base_tts.py:708-956).  Kept from the reference:
+      - phonetic mapping first (:721); segmentation per text with the memory-aware limit (:730-731)
+      - ``CancelledException`` is raised, not returned, at text / segment / iteration granularity (:727,754,771)
+      - ``ValueError`` propagates; ``RuntimeError`` mentioning "out of memory" or "length" and any other
+        exception fail only the segment they hit and are retried up to ``max_iterations`` (:786-797);
+        other ``RuntimeError`` propagate (:794)
+      - ``max_iterations == 1`` means no validation calls at all (:800)
+      - a text whose audio decays is regenerated whole, up to ``max_decay_retries`` times, with a seed taken
+        from the wall clock (:741-748, 926-941)
+      - per-item ``None`` on failure (:943-946); metadata: ``decay_ratio`` always, ``drift_prob`` = max and
+        ``text_similarity`` = min only when validation ran (:948-953)
+      - ``progress_callback("Generating segment i/n...")`` once per segment and attempt (:760-761)
+    """
+
+    def _run_pipeline(self, texts, cancellation_token, progress_callback=None):
+        token = cancellation_token
+        mapped = [self._apply_phonetic_mapping(t) for t in texts]
+        plans: List[List[str]] = []
+        for idx, text in enumerate(mapped):
+            if token.is_cancelled():
+                raise CancelledException(f"Cancelled during text item {idx}")
+            plans.append(self._split_text_into_segments(text, self._compute_max_chars()))
+        n = len(mapped)
+        final: List[Optional[torch.Tensor]] = [None] * n
+        seg_audio: List[List[torch.Tensor]] = [[] for _ in range(n)]
+        decay: List[Tuple[float, bool]] = [(0.0, True)] * n
+        scores: List[Tuple[List[float], List[float]]] = [([], []) for _ in range(n)]
+        pending = list(range(n))
+        for attempt in range(self.max_decay_retries):
+            if not pending:
+                break
+            if attempt > 0:
+                self.seed = int(time.time() * 1000) % 100000
+                logger.warning(f"  sound decay detected in {len(pending)} item(s), regenerating (attempt {attempt + 1}/{self.max_decay_retries})")
+            work = [(i, s, seg) for i in pending for s, seg in enumerate(plans[i])]
+            for i in pending:
+                seg_audio[i], scores[i] = [], ([], [])
+            got = self._generate_work(work, plans, token, progress_callback, scores)
+            for (i, s, _), a in zip(work, got):
+                if a is not None:
+                    seg_audio[i].append(a)
+            ready = [i for i in pending if seg_audio[i]]
+            finished = self._finish_items([seg_audio[i] for i in ready]) if ready else []
+            still = []
+            for i, res in zip(ready, finished):
+                if res is None:
+                    continue
+                final[i], ratio, ok = res
+                decay[i] = (ratio, ok)
+                logger.info(f"  Item {i + 1} sound decay ratio: {ratio:.3f} (threshold: {self.sound_decay_threshold})")
+                if not ok:
+                    still.append(i)
+            pending = still
+        out: List[Optional[Tuple[torch.Tensor, int, dict]]] = []
+        for i in range(n):
+            if final[i] is None or not seg_audio[i]:
+                logger.error(f"Item {i + 1} failed: no audio generated")
+                out.append(None)
+                continue
+            meta: Dict[str, float] = {}
+            if scores[i][0]:
+                meta["drift_prob"] = max(scores[i][0])
+            if scores[i][1]:
+                meta["text_similarity"] = min(scores[i][1])
+            meta["decay_ratio"] = decay[i][0]
+            out.append((final[i], len(seg_audio[i]), meta))
+        return out
+
+    # one entry of `work` per (item, segment index, text); returns the accepted audio (or None) per entry
+    def _generate_work(self, work, plans, token, progress_callback, scores):
+        accepted: List[Optional[torch.Tensor]] = [None] * len(work)
+        best: List[Optional[torch.Tensor]] = [None] * len(work)
+        best_drift = [float("inf")] * len(work)
+        last: List[Optional[torch.Tensor]] = [None] * len(work)
+        todo = list(range(len(work)))
+        bs = max(1, int(getattr(self, "batch_size", 1)))
+        for iteration in range(self.max_iterations):
+            if not todo:
+                break
+            if iteration > 0:
+                self.seed = int(time.time() * 1000) % 100000
+            retry: List[int] = []
+            for b0 in range(0, len(todo), bs):
+                chunk = todo[b0:b0 + bs]
+                for w in chunk:
+                    i, s, _ = work[w]
+                    if token.is_cancelled():
+                        raise CancelledException(f"Cancelled during segment {s + 1} of item {i + 1}")
+                    if progress_callback and iteration == 0:
+                        progress_callback(f"Generating segment {s + 1}/{len(plans[i])}...")
+                self._set_seeds()
+                audios = self._generate_chunk([work[w][2] for w in chunk], [work[w][0] for w in chunk], token)
+                for w, a in zip(chunk, audios):
+                    if a is None:
+                        retry.append(w)
+                        continue
+                    last[w] = a
+                    if self.max_iterations == 1:
+                        accepted[w] = a
+                        continue
+                    verdict = self._validate_segment(a, work[w][2])
+                    if verdict is None:                      # validation raised: counts as a failed attempt
+                        retry.append(w)
+                        continue
+                    drift, voice_ok, sim, text_ok = verdict
+                    if drift < best_drift[w]:
+                        best_drift[w], best[w] = drift, a
+                    i = work[w][0]
+                    if voice_ok and text_ok:
+                        accepted[w] = a
+                        scores[i][0].append(drift)
+                        if sim is not None:
+                            scores[i][1].append(sim)
+                    else:
+                        retry.append(w)
+            todo = retry
+        for w in todo:                                       # iterations exhausted: best by drift, else the last audio
+            accepted[w] = best[w] if best[w] is not None else last[w]
+            if best[w] is not None and best_drift[w] != float("inf"):
+                scores[work[w][0]][0].append(best_drift[w])
+        return accepted
+
+    def _generate_chunk(self, segs: List[str], item_idx: List[int], token) -> List[Optional[torch.Tensor]]:
+        """One batched ``_generate_audio`` call; on failure fall back to one call per segment so that the
+        reference's per-segment error policy decides who fails."""
+        try:
+            out = self._generate_audio(list(segs), item_ids=item_idx, cancellation_token=token)
+            return list(out)
+        except (ValueError, CancelledException):
+            raise
+        except Exception as first:  # noqa: BLE001
+            if len(segs) == 1:
+                return [self._classify(first)]
+        res: List[Optional[torch.Tensor]] = []
+        for seg, it in zip(segs, item_idx):
+            try:
+                res.append(self._generate_audio(seg, item_ids=[it], cancellation_token=token))
+            except (ValueError, CancelledException):
+                raise
+            except Exception as e:  # noqa: BLE001
+                res.append(self._classify(e))
+        return res
+
+    @staticmethod
+    def _classify(e: Exception):
+        if isinstance(e, RuntimeError):
+            msg = str(e).lower()
+            if "out of memory" in msg or "length" in msg:
+                logger.error(f"    segment OOM/length: {e}")
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
+                return None
+            raise e
+        logger.warning(f"    generation error ({e})")
+        return None
+
+    def _validate_segment(self, audio: torch.Tensor, text: str):
+        """Temp-WAV round trip through the reference's validators (base_tts.py:821-886); only reachable when
+        ``max_iterations > 1`` and the host package provides them."""
+        import os
+        import tempfile
+        if not hasattr(self, "_validate_accent_drift"):
+            return (0.0, True, None, True)
+        fd, path = tempfile.mkstemp(suffix=".wav", prefix="rho_tts_validate_")
+        os.close(fd)
+        try:
+            mono = audio.detach().cpu()
+            self._save_wav(path, mono.unsqueeze(0) if mono.dim() == 1 else mono, self.sample_rate)
+            drift, voice_ok = self._validate_accent_drift(path)
+            if hasattr(self, "_auto_sort_audio"):
+                self._auto_sort_audio(path, drift)
+            sim, text_ok = None, True
+            if voice_ok:
+                text_ok, sim, _ = self._validate_text_match(path, text)
+            return (drift, voice_ok, sim, text_ok)
+        except Exception as e:  # noqa: BLE001
+            logger.warning(f"    validation error ({e})")
+            return None
+        finally:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+
+class HipAudioLeaves:
+    """The numeric leaves of the pipeline as calls into the fused HIP kernel (one stage mask each).
+    Reference: base_tts.py:297-536, providers/qwen.py:268-378.  Inputs may be CPU or GPU tensors; the result lives
+    where the input lived."""
+
+    def _post_params(self, stages: int) -> _native.PostParams:
+        return _native.make_post_params(
+            sample_rate=self.sample_rate, silence_threshold_db=self.silence_threshold_db,
+            fade_duration_sec=self.fade_duration_sec, crossfade_duration_sec=self.crossfade_duration_sec,
+            inter_sentence_pause_sec=self.inter_sentence_pause_sec, trim_silence=self.trim_silence,
+            sound_decay_threshold=getattr(self, "sound_decay_threshold", 0.3), stages=stages)
+
+    def _post(self, items, stages, seg_trim=None):
+        return self._native_ctx().post_process(self._post_params(stages), items, seg_trim)
+
+    def _trim_silence(self, audio: torch.Tensor, from_start: bool = True, from_end: bool = True) -> torch.Tensor:
+        if not self.trim_silence or audio.numel() == 0:
+            return audio
+        st = (_native.POST_TRIM_START if from_start else 0) | (_native.POST_TRIM_END if from_end else 0)
+        if st == 0:
+            return audio.reshape(-1) if audio.dim() == 2 else audio
+        (out,), (s,) = self._post([[audio]], st)
+        return out.unsqueeze(0) if s.all_silent else out       # the reference returns a (1, window) view for silence (:379-380)
+
+    def _remove_dc_offset(self, audio: torch.Tensor) -> torch.Tensor:
+        if audio.numel() == 0:
+            return audio
+        (out,), _ = self._post([[audio]], _native.POST_DC)
+        return out.view(audio.shape)
+
+    def _apply_fades(self, audio: torch.Tensor, fade_in: bool = True, fade_out: bool = True) -> torch.Tensor:
+        if audio.numel() == 0:
+            return audio
+        st = (_native.POST_FADE_IN if fade_in else 0) | (_native.POST_FADE_OUT if fade_out else 0)
+        (out,), _ = self._post([[audio]], st)
+        return out.view(audio.shape)
+
+    def _smooth_segment_join(self, audio_segments):
+        if len(audio_segments) == 0:
+            return None
+        st = _native.POST_PIPELINE & ~(_native.POST_LOUDNESS | _native.POST_DECAY)
+        (out,), (s,) = self._post([list(audio_segments)], st)
+        return out.unsqueeze(0) if s.all_silent else out
+
+    def _post_process_audio(self, audio: torch.Tensor) -> torch.Tensor:
+        (out,), _ = self._post([[audio]], _native.POST_LOUDNESS)
+        return out.view(audio.shape)
+
+    def _validate_sound_decay(self, audio: torch.Tensor) -> tuple:
+        if audio.numel() == 0:
+            return 1.0, True
+        _, (s,) = self._post([[audio]], _native.POST_DECAY)
+        return s.decay_ratio, bool(s.decay_ok)
+
+    def _finish_items(self, items: Sequence[Sequence[torch.Tensor]]):
+        """join -> loudness -> decay for every item, one launch (base_tts.py:912-926)."""
+        outs, stats = self._post([list(it) for it in items], _native.POST_PIPELINE)
+        return [(o.unsqueeze(0) if s.all_silent else o, s.decay_ratio, bool(s.decay_ok)) for o, s in zip(outs, stats)]
+
+
+class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
+    """Qwen3-TTS generation on one MI355X.  Same keyword arguments as the reference's ``QwenTTS``."""
+
+    MAX_MODEL_CHARS = 4000
+    BYTES_PER_CHAR_ESTIMATE = 500_000
+
+    def __init__(self, device: str = "cuda", seed: int = 789, deterministic: bool = False,
+                 reference_audio: Optional[str] = None, reference_text: Optional[str] = None, speaker: Optional[str] = None,
+                 language: str = "English", model_path: str = "Qwen/Qwen3-TTS-12Hz-1.7B-Base",
+                 max_chars_per_segment: Optional[int] = None, batch_size: int = 32, max_iterations: int = 1,
+                 accent_drift_threshold: float = 0.17, text_similarity_threshold: float = 0.85,
+                 sound_decay_threshold: float = 0.3, drift_model_path: Optional[str] = None,
+                 phonetic_mapping: Optional[Dict[str, str]] = None):
+        super().__init__(device, seed, deterministic, phonetic_mapping=phonetic_mapping)
+        if reference_audio is not None and reference_text is None:
+            raise ValueError("reference_text (transcript of reference audio) is required when reference_audio is set")
+        if not str(device).startswith("cuda"):
+            raise ValueError("MI355XQwenTTS runs on an AMD GPU only (device='cuda' or 'cuda:N'); there is no CPU path")
+        self.reference_audio_path = reference_audio
+        self.reference_text = reference_text
+        self.speaker = speaker
+        self.language = language
+        self.voice_cloning = reference_audio is not None
+        self.model_path = model_path
+        self.drift_model_path = drift_model_path
+        self._max_chars_explicit = max_chars_per_segment is not None
+        self.max_chars_per_segment = max_chars_per_segment if max_chars_per_segment is not None else 1000
+        self.batch_size = batch_size
+        self.force_sentence_split = False
+        self.max_iterations = max_iterations
+        self.accent_drift_threshold = accent_drift_threshold
+        self.text_similarity_threshold = text_similarity_threshold
+        self.sound_decay_threshold = sound_decay_threshold
+        self._engine = None
+        self._ctx = None
+        self._lock = threading.RLock()
+        self._voice_key = None
+
+    # ---------------------------------------------------------------- native handles
+    def _device_ordinal(self) -> int:
+        d = str(self.device)
+        return int(d.split(":")[1]) if ":" in d else 0
+
+    def _native_ctx(self):
+        eng = self._engine
+        if eng is not None:
+            return eng.ctx
+        if self._ctx is None:
+            self._ctx = _native.Context(self._device_ordinal())
+        return self._ctx
+
+    def _load_engine(self):
+        with self._lock:
+            if self._engine is None:
+                from .engine import Engine
+                if self._ctx is not None:
+                    self._ctx.close()
+                    self._ctx = None
+                self._engine = Engine(self.model_path, self._device_ordinal(), max_batch=max(1, min(64, int(self.batch_size))))
+                self._max_model_chars = min(self.MAX_MODEL_CHARS, self._engine.cfg.max_positions)
+            return self._engine
+
+    def _ensure_voice(self, eng) -> None:
+        is_custom = "CustomVoice" in self.model_path
+        if is_custom and not self.speaker:
+            raise ValueError("CustomVoice model requires a named speaker. Select a built-in voice (e.g. Vivian, Ryan) "
+                             "or provide reference audio with a Base model for voice cloning.")
+        if not is_custom and not self.voice_cloning:
+            raise ValueError("Qwen Base model requires reference audio for voice cloning. "
+                             "Use a CustomVoice model with a named speaker, or provide reference audio.")
+        key = (self.speaker, self.language) if is_custom else (self.reference_audio_path, self.reference_text, self.language)
+        if key == self._voice_key:
+            return
+        if is_custom:
+            eng.set_builtin_voice(self.speaker, self.language)
+        else:
+            eng.set_voice_from_audio(self.reference_audio_path, self.reference_text, self.language)
+        self._voice_key = key
+
+    # ---------------------------------------------------------------- provider contract
+    def _generate_audio(self, text: Union[str, List[str]], **kwargs) -> Union[torch.Tensor, List[torch.Tensor]]:
+        single = isinstance(text, str)
+        texts = [text] if single else list(text)
+        eng = self._load_engine()
+        token = kwargs.get("cancellation_token")
+        flag = C.c_int32(0)
+        stop = threading.Event()
+        watcher = None
+        if token is not None:                                   # forward CancellationToken.cancel() into the native frame loop
+            def watch():
+                while not stop.wait(0.02):
+                    if token.is_cancelled():
+                        flag.value = 1
+                        return
+            watcher = threading.Thread(target=watch, daemon=True)
+            watcher.start()
+        try:
+            with self._lock:
+                self._ensure_voice(eng)
+                wavs = eng.synthesize(texts, seed=int(self.seed), item_ids=kwargs.get("item_ids"), cancel_flag=flag)
+        except _native.CancelledError as e:
+            raise CancelledException(str(e))
+        finally:
+            stop.set()
+            if watcher is not None:
+                watcher.join(timeout=1.0)
+        return wavs[0] if single else wavs
+
+    @property
+    def sample_rate(self) -> int:
+        return 24000 if self._engine is None else self._engine.cfg.sample_rate
+
+    def close(self) -> None:
+        with self._lock:
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = None
+            if self._ctx is not None:
+                self._ctx.close()
+                self._ctx = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+    @classmethod
+    def provider_info(cls) -> ProviderInfo:
+        return ProviderInfo(name=PROVIDER_NAME, supports_voice_cloning=True,
+                            supported_languages=["English", "Chinese", "Japanese", "Korean"],
+                            builtin_voices=[VoiceInfo(id=v, name=v, language="English") for v in BUILTIN_VOICES])
+
+
+def register(name: str = PROVIDER_NAME) -> str:
+    """``TTSFactory.register_provider(name, MI355XQwenTTS)`` on whichever host API is active (see api.py)."""
+    TTSFactory.register_provider(name, MI355XQwenTTS)
+    return name

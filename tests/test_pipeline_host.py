@@ -1,0 +1,267 @@
+"""Host logic of the provider against the reference-generated pipeline fixtures
+(tests/golden/pipeline_golden.json, produced by tests/golden/make_golden.py from the reference's own
+BaseTTS._run_pipeline with a deterministic fake provider).  The numeric leaves are supplied by the CPU
+oracle here (no GPU in this suite); tests/test_provider_gpu.py repeats the comparison with the HIP leaves."""
+import json
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess as OP
+from rho_tts_amd import hostapi
+from rho_tts_amd.provider import BatchedPipeline
+
+SR = 24000
+torch.set_num_threads(1)
+
+
+def fake_wave(text: str) -> np.ndarray:          # must stay identical to tests/golden/make_golden.py
+    n = 12000 + 480 * (len(text) % 50)
+    f = 180.0 + 7.0 * (sum(map(ord, text)) % 40)
+    i = np.arange(n, dtype=np.float64)
+    lead = 1200 + 37 * (len(text) % 11)
+    env = np.ones(n)
+    env[:lead] = 0.0
+    env[-lead:] = 0.0
+    return ((0.25 * np.sin(2 * np.pi * f * i / SR) + 0.005) * env).astype(np.float32)
+
+
+class OracleLeaves:
+    def _finish_items(self, items):
+        p = OP.PostParams(sample_rate=self.sample_rate, sound_decay_threshold=self.sound_decay_threshold,
+                          inter_sentence_pause_sec=self.inter_sentence_pause_sec)
+        return [OP.finish_item(list(it), p, loudness=False) for it in items]
+
+
+class Fake(BatchedPipeline, OracleLeaves, hostapi.BaseTTS):
+    def __init__(self, batch_size=1, **kw):
+        super().__init__(device="cpu", **kw)
+        self.batch_size = batch_size
+        self.calls, self.fail_on, self.oom_on, self.value_error_on = [], set(), set(), set()
+
+    def _generate_audio(self, text, **kwargs):
+        texts = [text] if isinstance(text, str) else list(text)
+        out = []
+        for t in texts:
+            self.calls.append(t)
+            if t in self.value_error_on:
+                raise ValueError("bad configuration")
+            if t in self.fail_on:
+                raise OSError("synthetic failure")
+            if t in self.oom_on:
+                raise RuntimeError("HIP out of memory")
+            out.append(torch.from_numpy(fake_wave(t)))
+        return out[0] if isinstance(text, str) else out
+
+    @property
+    def sample_rate(self):
+        return SR
+
+
+def run(tts, texts, token=None, cb=None):
+    res = tts._run_pipeline(texts, token or hostapi.CancellationToken(), cb)
+    rec = []
+    for r in res:
+        if r is None:
+            rec.append(None)
+        else:
+            a, nseg, meta = r
+            a = a.reshape(-1).numpy()
+            rec.append({"len": int(a.shape[0]), "segments": int(nseg), "abs_sum": float(np.abs(a.astype(np.float64)).sum()),
+                        "decay_ratio": float(meta["decay_ratio"]), "meta_keys": sorted(meta.keys())})
+    return rec
+
+
+def same(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if w is None:
+            assert g is None
+            continue
+        assert g["len"] == w["len"] and g["segments"] == w["segments"] and g["meta_keys"] == w["meta_keys"]
+        assert abs(g["abs_sum"] - w["abs_sum"]) < 1e-6 * w["abs_sum"]
+        assert abs(g["decay_ratio"] - w["decay_ratio"]) < 1e-9
+
+
+@pytest.mark.parametrize("bs", [1, 3, 32])
+def test_pipeline_cases_match_reference(golden_pipe, bs):
+    g = golden_pipe
+    t = Fake(batch_size=bs); t._max_chars_explicit = True
+    same(run(t, g["single_one_segment"]["texts"]), g["single_one_segment"]["out"])
+    assert t.calls == g["single_one_segment"]["calls"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True
+    same(run(t, g["three_segments_forced"]["texts"]), g["three_segments_forced"]["out"])
+    assert t.calls == g["three_segments_forced"]["calls"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True; t.force_sentence_split = False; t.max_chars_per_segment = 30
+    same(run(t, g["max_chars_30"]["texts"]), g["max_chars_30"]["out"])
+    assert t.calls == g["max_chars_30"]["calls"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True; t.phonetic_mapping = {"exocrine": "exo-crene"}
+    same(run(t, g["phonetic"]["texts"]), g["phonetic"]["out"])
+    assert t.calls == g["phonetic"]["calls"]                         # the mapped text reaches _generate_audio
+
+
+@pytest.mark.parametrize("bs", [1, 4, 32])
+def test_failures_are_isolated_per_item(golden_pipe, bs):
+    c = golden_pipe["eight_one_fails"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True
+    t.fail_on, t.oom_on = {c["texts"][3]}, {c["texts"][6]}
+    msgs = []
+    same(run(t, c["texts"], cb=msgs.append), c["out"])
+    assert msgs == c["progress"]
+    assert sorted(set(t.calls)) == sorted(set(c["calls"]))           # every text was attempted
+
+
+def test_split_text_matches_reference(golden_pipe):
+    for key, want in golden_pipe["split_text"].items():
+        fs, mc, txt = key.split("|", 2)
+        assert hostapi.split_text_into_segments(txt, int(mc), bool(int(fs))) == want, key
+
+
+def test_value_error_propagates_and_other_runtime_errors_too():
+    t = Fake(); t._max_chars_explicit = True
+    t.value_error_on = {"b"}
+    with pytest.raises(ValueError):
+        t._run_pipeline(["a", "b"], hostapi.CancellationToken())
+    with pytest.raises(ValueError):
+        t.generate(["a", "b"])                                        # generate() re-raises ValueError (base_tts.py:1096-1097)
+
+    class Boom(Fake):
+        def _generate_audio(self, text, **kw):
+            raise RuntimeError("device lost")
+    with pytest.raises(RuntimeError):
+        Boom()._run_pipeline(["a"], hostapi.CancellationToken())
+    assert Boom().generate("a") is None                                # ... but generate() swallows it and returns None
+
+
+def test_cancellation_raises_inside_and_returns_none_outside():
+    t = Fake(batch_size=2); t._max_chars_explicit = True
+    tok = hostapi.CancellationToken()
+    tok.cancel()
+    with pytest.raises(hostapi.CancelledException):
+        t._run_pipeline(["a", "b"], tok)
+    assert t.generate(["a", "b"], cancellation_token=tok) is None
+    tok2 = hostapi.CancellationToken()
+    t2 = Fake(batch_size=1); t2._max_chars_explicit = True
+    seen = []
+
+    def cb(msg):
+        seen.append(msg)
+        if len(seen) == 2:
+            tok2.cancel()
+    with pytest.raises(hostapi.CancelledException):
+        t2._run_pipeline(["One.", "Two.", "Three.", "Four."], tok2, cb)
+    assert len(t2.calls) == 2                                          # cancelled between segments, nothing further generated
+
+
+def test_decay_retry_regenerates_whole_item_then_gives_best():
+    class Decaying(Fake):
+        def _generate_audio(self, text, **kw):
+            out = super()._generate_audio(text, **kw)
+            fix = lambda a: a * torch.linspace(1.0, 0.0, a.numel()) if self.seed == 789 else a
+            return fix(out) if isinstance(text, str) else [fix(a) for a in out]
+    t = Decaying(); t._max_chars_explicit = True
+    res = t._run_pipeline(["Hello world"], hostapi.CancellationToken())
+    assert len(t.calls) == 2 and t.seed != 789                          # one regeneration with a wall-clock seed
+    assert res[0][2]["decay_ratio"] >= 0.3
+
+    class Always(Fake):
+        def _generate_audio(self, text, **kw):
+            out = super()._generate_audio(text, **kw)
+            f = lambda a: a * torch.linspace(1.0, 0.0, a.numel())
+            return f(out) if isinstance(text, str) else [f(a) for a in out]
+    t = Always(); t._max_chars_explicit = True
+    res = t._run_pipeline(["Hello world"], hostapi.CancellationToken())
+    assert len(t.calls) == t.max_decay_retries and res[0] is not None and res[0][2]["decay_ratio"] < 0.3
+
+
+def test_validation_loop_only_runs_when_max_iterations_gt_1():
+    calls = {"drift": 0, "text": 0}
+
+    class V(Fake):
+        def _validate_accent_drift(self, path):
+            calls["drift"] += 1
+            return (0.5, False) if calls["drift"] == 1 else (0.05, True)
+
+        def _validate_text_match(self, path, text):
+            calls["text"] += 1
+            return True, 0.93, text
+    t = V(); t._max_chars_explicit = True
+    t._run_pipeline(["Hello"], hostapi.CancellationToken())
+    assert calls == {"drift": 0, "text": 0}                              # max_iterations == 1: no validation at all
+    t = V(); t._max_chars_explicit = True; t.max_iterations = 3
+    res = t._run_pipeline(["Hello"], hostapi.CancellationToken())
+    assert calls == {"drift": 2, "text": 1} and len(t.calls) == 2
+    assert res[0][2]["drift_prob"] == 0.05 and res[0][2]["text_similarity"] == 0.93
+    assert sorted(res[0][2]) == ["decay_ratio", "drift_prob", "text_similarity"]
+
+
+def test_generate_modes_and_files(tmp_path):
+    t = Fake(batch_size=8); t._max_chars_explicit = True
+    r = t.generate("Hello there")
+    assert isinstance(r, hostapi.GenerationResult) and r.path is None and r.sample_rate == SR and r.segments_count == 1
+    assert abs(r.duration_sec - r.audio.numel() / SR) < 1e-9 and r.decay_ratio is not None and r.drift_prob is None
+    rs = t.generate(["One", "Two"], output_path=str(tmp_path / "out"))
+    assert [x.path for x in rs] == [str(tmp_path / "out_0.wav"), str(tmp_path / "out_1.wav")]
+    import wave
+    with wave.open(rs[0].path) as wf:
+        assert wf.getframerate() == SR and wf.getnchannels() == 1 and wf.getsampwidth() == 2
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2")
+    assert np.array_equal(pcm, OP.pcm16(rs[0].audio))
+    one = t.generate("Solo", output_path=str(tmp_path / "solo.wav"))
+    assert one.path == str(tmp_path / "solo.wav")
+    with pytest.raises(hostapi.FormatConversionError):
+        t.generate("x", format="aiff")
+    t.fail_on = {"bad"}
+    assert t.generate("bad") is None and t.generate(["bad", "bad"]) is None
+    mixed = t.generate(["bad", "good"])
+    assert mixed[0] is None and mixed[1] is not None
+
+
+def test_factory_registration_contract():
+    saved = dict(hostapi.TTSFactory._providers)
+    try:
+        hostapi.TTSFactory.register_provider("fake", Fake)
+        assert "fake" in hostapi.TTSFactory.list_providers()
+        assert isinstance(hostapi.TTSFactory.get_tts_instance("fake", batch_size=2), Fake)
+        with pytest.raises(TypeError):
+            hostapi.TTSFactory.register_provider("nope", dict)
+        with pytest.raises(hostapi.ProviderNotFoundError):
+            hostapi.TTSFactory.get_tts_instance("missing")
+        hostapi.TTSFactory.register_provider("fake", Fake)              # last write wins, silently
+    finally:
+        hostapi.TTSFactory._providers = saved
+
+
+def test_async_and_token_threading():
+    import asyncio
+    t = Fake(); t._max_chars_explicit = True
+    r = asyncio.run(t.async_generate("Hello"))
+    assert r is not None and r.audio.numel() > 0
+    tok = hostapi.CancellationToken()
+    th = threading.Thread(target=tok.cancel)
+    th.start(); th.join()
+    assert tok.is_cancelled()
+    tok.reset()
+    assert not tok.is_cancelled()
+    with pytest.raises(hostapi.CancelledException):
+        tok.cancel(); tok.raise_if_cancelled()
+
+
+def test_provider_constructor_contract_without_gpu():
+    from rho_tts_amd.provider import MI355XQwenTTS, PROVIDER_NAME, register
+    with pytest.raises(ValueError):
+        MI355XQwenTTS(reference_audio="x.wav")                          # reference_text is required with reference_audio
+    with pytest.raises(ValueError):
+        MI355XQwenTTS(device="cpu")                                     # no CPU path, said loudly
+    p = MI355XQwenTTS(speaker="Ryan", model_path="Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice")
+    assert p.sample_rate == 24000 and p.batch_size == 32 and p.force_sentence_split is False and p.max_iterations == 1
+    assert p.voice_cloning is False and p.provider_info().supports_voice_cloning
+    from rho_tts_amd import api
+    saved = dict(api.TTSFactory._providers)
+    try:
+        assert register() == PROVIDER_NAME and PROVIDER_NAME in api.TTSFactory.list_providers()
+        assert issubclass(MI355XQwenTTS, api.BaseTTS)
+    finally:
+        api.TTSFactory._providers = saved
