@@ -125,7 +125,8 @@ class BatchedPipeline:
                     if progress_callback and iteration == 0:
                         progress_callback(f"Generating segment {s + 1}/{len(plans[i])}...")
                 self._set_seeds()
-                audios = self._generate_chunk([work[w][2] for w in chunk], [work[w][0] for w in chunk], token)
+                # RNG stream of a segment = its index in the work list: independent of how the list is cut into batches
+                audios = self._generate_chunk([work[w][2] for w in chunk], list(chunk), token)
                 for w, a in zip(chunk, audios):
                     if a is None:
                         retry.append(w)
