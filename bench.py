@@ -48,6 +48,14 @@ def sentences(n: int, n_words, seed: int):
     return out
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +88,7 @@ def main():
     from rho_tts_amd.dist import broadcast_voice, gather_waveforms
 
     cfg = config.PRESETS[args.model]()
+    log(f"rank {rank}/{world}: building {cfg.name} engine (synthetic weights) ...")
     eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=local_rank, max_batch=args.batch)
     if args.greedy:
         eng.params.do_sample = False
@@ -106,8 +115,10 @@ def main():
             host = [o.cpu() for o in outs]
         return audio_s, host
 
+    log(f"engine ready: {eng.model.weight_bytes() / 1e9:.2f} GB of weights; warmup x{args.warmup}")
     for _ in range(args.warmup):
         step()
+        log("warmup step done")
 
     def sync():
         if dist is not None:
@@ -123,6 +134,7 @@ def main():
         audio_local += a
     sync()
     dt = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {dt:.3f} s")
     t = torch.tensor([dt, audio_local], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = t.clone()
@@ -200,6 +212,7 @@ def cpu_baseline(cfg, args, eng):
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    log(f"cpu baseline: copying weights to the host ({cores} cores) ...")
     state = {k: v.cpu() for k, v in synthetic_state(cfg, 789, device=eng.device).items()}
     om = OracleModel(cfg, state)
     del state
@@ -210,10 +223,12 @@ def cpu_baseline(cfg, args, eng):
     cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode("time year people way day"), "english")
     v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
     ids = [eng.tokenizer.encode(t) for t in texts]
+    log("cpu baseline: oracle decode running ...")
     t0 = time.perf_counter()
     with torch.no_grad():
         codes = om.generate(v, ids, [frames] * B, SamplingParams(True, 0.9, 50, 1.0, 1.05), seed=789)
         q = cfg.codec.num_quantizers
+        log(f"cpu baseline: decode done after {time.perf_counter() - t0:.1f} s, codec decoder ...")
         wav = om.code2wav(torch.stack([c[:, :q].T for c in codes]))
         p = OP.PostParams(sample_rate=cfg.sample_rate)
         for b in range(B):

@@ -53,6 +53,10 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
     with _lib_lock:
         if _lib is not None:
             return _lib
+        # torch ships its own copies of the HIP/HSA runtime; whichever copy is mapped first owns the GPU, and a
+        # second HSA runtime in the process then sees "No HIP GPUs".  Importing torch first makes this library
+        # resolve libamdhip64.so.7 to the copy torch already mapped.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             if not build_if_missing:
                 raise NativeUnavailable(f"{LIB_PATH} not found; run `python -m rho_tts_amd._build`")

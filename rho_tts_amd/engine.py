@@ -98,7 +98,8 @@ class Engine:
         cap = int(self.params.max_seconds * self.cfg.frame_rate)
         if self.synthetic:
             n_words = max(1, len(text.split()))
-            return max(2, min(cap, int(round(self.cfg.frame_rate * FRAME_SECONDS_PER_WORD * n_words))))
+            rate = min(self.cfg.frame_rate, 12.5)          # test configs have toy codecs with absurd frame rates
+            return max(2, min(cap, int(round(rate * FRAME_SECONDS_PER_WORD * n_words))))
         return max(2, min(cap, 8 + 6 * n_tokens))            # eos-terminated; generous cap of ~0.5 s per token
 
     # ------------------------------------------------------------------ generate
