@@ -202,7 +202,7 @@ def main():
 
 def cpu_baseline(cfg, args, eng):
     """The CPU oracle (oracle/model.py, a port — the reference's own CPU path needs the absent qwen-tts package) timed on
-    this box's host cores on a bounded sample of the same workload: same model shape and batch, 2-s reference clip, 4 decoded
+    this box's host cores on a bounded sample of the same workload: same model shape and batch, 2-s reference clip, 3 decoded
     frames + their codec decode + post-processing.  Reported beside the GPU number, never as the target."""
     from oracle import postprocess as OP
     from oracle.model import OracleModel, Voice
@@ -210,14 +210,14 @@ def cpu_baseline(cfg, args, eng):
     from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
     from rho_tts_amd.weights import synthetic_state
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)          # eager PyTorch stops scaling (and small ops get slower) past ~32 threads
     torch.set_num_threads(cores)
     log(f"cpu baseline: copying weights to the host ({cores} cores) ...")
     state = {k: v.cpu() for k, v in synthetic_state(cfg, 789, device=eng.device).items()}
     om = OracleModel(cfg, state)
     del state
     B = args.batch if cfg.talker.hidden <= 1024 else min(args.batch, 32)
-    frames = 4
+    frames = 3
     texts = sentences(B, args.words, seed=789)
     clip = synthetic_reference_clip(2.0, cfg.sample_rate, 789)
     cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode("time year people way day"), "english")

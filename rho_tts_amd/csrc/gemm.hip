@@ -7,6 +7,8 @@
 //   k_gemm_tiled    128x128x32 LDS-staged implicit GEMM for prefill and the codec decoder's
 //                   conv-as-GEMM contractions (causal dilated conv1d, transposed conv1d), fused
 //                   bias / activation / layer-scale / residual / SnakeBeta epilogue.  MFMA-bound.
+#include <hip/hip_ext.h>
+
 #include "kernels.h"
 
 namespace {
@@ -345,16 +347,20 @@ int skinny_pick_split(int M, int N, int K, int n_cu) {
     return s;
 }
 
-int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k) {
+int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
+                       hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (M < 1 || M > 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: M=%d outside 1..64", M);
     if (w.K != w.Kp) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: K=%d must be a multiple of 16", w.K);
     const int NT = w.Np / 32, KT = w.Kp / 16;
     if (split_k < 1 || KT % split_k) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: split_k=%d does not divide %d k-tiles", split_k, KT);
     dim3 grid((NT + 3) / 4, split_k);
+    // hipExtLaunchKernelGGL stamps the events at the kernel's own begin/end on the device (no launch gaps inside)
     if (M <= 32)
-        hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+        hipExtLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
+                              KT / split_k, d_out, ldc, w.N);
     else
-        hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+        hipExtLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
+                              KT / split_k, d_out, ldc, w.N);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

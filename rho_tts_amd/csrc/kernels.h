@@ -57,7 +57,8 @@ size_t packed_bytes(int N, int K);
 int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
 int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e);
 // Weight-streaming form for M <= 64 rows (decode): plain bf16 A [M][K], raw f32 slabs out.
-int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k);
+int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int skinny_pick_split(int M, int N, int K, int n_cu);
 
 // ---------------------------------------------------------------------------------- row kernels

@@ -265,38 +265,40 @@ int bind_stack(rt_model* m, StackW& S, const char* p, const rt_stack_dims& d, in
     return RT_OK;
 }
 
-// ---- profiling brackets around weight-streaming GEMM launches
-struct ProfScope {
-    rt_model* m;
-    hipEvent_t stop = nullptr;
-    ProfScope(rt_model* mm, double bytes) : m(mm) {
-        if (!m->prof) return;
-        if (m->prof_used >= m->prof_ev.size()) {
-            if (m->prof_ev.size() >= 400000) return;
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            m->prof_ev.push_back({a, b});
-        }
-        auto& pr = m->prof_ev[m->prof_used++];
-        (void)hipEventRecord(pr.first, m->ctx->stream);
-        stop = pr.second;
-        m->prof_bytes += bytes;
+// ---- device-side begin/end stamps of weight-streaming GEMM launches (hipExtLaunchKernelGGL events)
+bool prof_events(rt_model* m, double bytes, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
+    if (!m->prof) return false;
+    if (m->prof_used >= m->prof_ev.size()) {
+        if (m->prof_ev.size() >= 400000) return false;
+        hipEvent_t x, y;
+        if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return false;
+        m->prof_ev.push_back({x, y});
     }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, m->ctx->stream); }
-};
+    auto& pr = m->prof_ev[m->prof_used++];
+    *a = pr.first;
+    *b = pr.second;
+    m->prof_bytes += bytes;
+    return true;
+}
 
 // rows x K (bf16) times W^T -> raw f32 slabs [n_slabs][rows][N]
 int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* slabs, int* n_slabs) {
     if (rows <= 64) {
         const int S = skinny_pick_split(rows, W.N, W.K, m->ctx->n_cu);
-        ProfScope ps(m, (double)W.N * W.K * 2.0);
-        RT_TRY(launch_gemm_skinny(m->ctx, A, rows, W, slabs, W.N, S));
+        hipEvent_t e0, e1;
+        prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
+        RT_TRY(launch_gemm_skinny(m->ctx, A, rows, W, slabs, W.N, S, e0, e1));
         *n_slabs = S;
     } else {
+        // prefill: a few hundred rows give only a handful of 128x128 tiles; split K until the grid covers the chip
+        const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);
+        int S = 1;
+        while (S < 8 && tiles * S < m->ctx->n_cu && W.K / (S * 2) >= 256) S *= 2;
         GemmA a; a.ptr = A; a.is_f32 = 0; a.M = rows; a.Cin = W.K; a.taps = 1;
-        GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = 1;
+        GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = S;
         RT_TRY(launch_gemm(m->ctx, a, W, e));
-        *n_slabs = 1;
+        *n_slabs = S;
     }
     return RT_OK;
 }
@@ -310,7 +312,7 @@ struct StackWs {
 };
 size_t slab_floats(const rt_stack_dims& d, int M) {
     const size_t widest = std::max<size_t>((size_t)2 * d.inter, (size_t)(d.heads + 2 * d.kv_heads) * d.head_dim);
-    return std::max<size_t>((size_t)M * widest, (size_t)64 * 32768);
+    return std::max<size_t>((size_t)M * widest * (M > 64 ? 8 : 1), (size_t)64 * 32768);
 }
 int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w) {
     RT_TRY(pool_arr(m, (size_t)M * d.hidden, &w->xn));

@@ -17,48 +17,79 @@ __device__ __forceinline__ float block_sum_f32(float v, float* sh) {
     return t;
 }
 
-// x += scale * (sum_s slab[s] + slab_bias); xn = rmsnorm(x) * w.   One workgroup (256) per row.
+// x += scale * (sum_s slab[s] + slab_bias); xn = rmsnorm(x) * w.   One workgroup (256) per row, 16-B accesses,
+// the row kept in registers between the reduction and the normalisation (H <= 8192, H % 4 == 0).
 __global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int H, const float* __restrict__ slabs, int n_slabs,
                                                      int64_t slab_stride, const float* __restrict__ slab_bias,
                                                      const float* __restrict__ scale, const float* __restrict__ w, float eps,
                                                      bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
     __shared__ float sh[4];
+    constexpr int MAXV = 8;
     const int64_t row = blockIdx.x;
-    float* xr = x + row * H;
+    const int nv = H >> 2;
+    f4_t* xr = reinterpret_cast<f4_t*>(x + row * H);
+    f4_t keep[MAXV];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < H; i += 256) {
-        float v = xr[i];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i >= nv) break;
+        f4_t v = xr[i];
         if (n_slabs > 0) {
-            float a = slab_bias ? slab_bias[i] : 0.f;
-            for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + row * H + i];
-            if (scale) a *= scale[i];
+            f4_t a = {0.f, 0.f, 0.f, 0.f};
+            if (slab_bias) a = reinterpret_cast<const f4_t*>(slab_bias)[i];
+            const f4_t* sp = reinterpret_cast<const f4_t*>(slabs + row * H) + i;
+            const int64_t st4 = slab_stride >> 2;
+#pragma unroll 8
+            for (int s = 0; s < n_slabs; ++s) a += sp[s * st4];
+            if (scale) a *= reinterpret_cast<const f4_t*>(scale)[i];
             v += a;
             xr[i] = v;
         }
-        ss += v * v;
+        keep[j] = v;
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     if (!w) return;
     const float tot = block_sum_f32(ss, sh);
     const float inv = rsqrtf(tot / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) {
-        const float v = w[i] * (xr[i] * inv);
-        if (out_bf16) out_bf16[row * H + i] = f32_to_bf16(v);
-        if (out_f32) out_f32[row * H + i] = v;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i >= nv) break;
+        const f4_t wv = reinterpret_cast<const f4_t*>(w)[i];
+        f4_t v = keep[j];
+        v[0] = wv[0] * (v[0] * inv); v[1] = wv[1] * (v[1] * inv); v[2] = wv[2] * (v[2] * inv); v[3] = wv[3] * (v[3] * inv);
+        if (out_f32) reinterpret_cast<f4_t*>(out_f32 + row * H)[i] = v;
+        if (out_bf16) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            reinterpret_cast<uint2*>(out_bf16 + row * H)[i] = pk;
+        }
     }
 }
 
 __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
-                           int64_t total) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = idx / I;
-        const int i = (int)(idx - m * I);
-        float g = 0.f, u = 0.f;
+                           int64_t total4) {
+    const int I4 = I >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / I4;
+        const int i = (int)(idx - m * I4);
+        f4_t g = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+        const f4_t* p = reinterpret_cast<const f4_t*>(slabs + m * 2 * I);
+        const int64_t st4 = slab_stride >> 2;
+#pragma unroll 8
         for (int s = 0; s < n_slabs; ++s) {
-            const float* p = slabs + s * slab_stride + m * 2 * I;
-            g += p[i];
-            u += p[I + i];
+            g += p[s * st4 + i];
+            u += p[s * st4 + I4 + i];
         }
-        out[idx] = f32_to_bf16(g / (1.f + __expf(-g)) * u);
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16(r[0]) | ((unsigned)f32_to_bf16(r[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16(r[2]) | ((unsigned)f32_to_bf16(r[3]) << 16);
+        reinterpret_cast<uint2*>(out)[idx] = pk;
     }
 }
 
@@ -246,6 +277,7 @@ inline unsigned grid_for(int64_t total, int block = 256) {
 int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, int n_slabs, const float* slab_bias,
                        const float* scale, const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
     if (M <= 0) return RT_OK;
+    if (H % 4 || H > 8192) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rmsnorm: hidden size %d unsupported (multiple of 4, <= 8192)", H);
     hipLaunchKernelGGL(k_add_rmsnorm, dim3(M), dim3(256), 0, ctx->stream, x, H, slabs, n_slabs, (int64_t)M * H, slab_bias, scale, w,
                        eps, out_bf16, out_f32);
     RT_HIP(ctx, hipGetLastError());
@@ -253,9 +285,10 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
 }
 
 int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out) {
-    const int64_t total = (int64_t)M * I;
+    const int64_t total = (int64_t)M * I / 4;
     if (total <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_silu_mul, dim3(grid_for(total)), dim3(256), 0, ctx->stream, slabs, n_slabs, (int64_t)M * 2 * I, I, out, total);
+    if (I % 4) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "silu_mul: intermediate size %d not a multiple of 4", I);
+    hipLaunchKernelGGL(k_silu_mul, dim3(grid_for(total, 64)), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * 2 * I, I, out, total);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
             // ---- radix select: key of the k-th largest value
             unsigned prefix = 0, mask = 0;
             int remaining = k;
+            if (tid == 0) sh_u[6] = 0;
             for (int pass = 3; pass >= 0; --pass) {
                 hist[tid] = 0;
                 __syncthreads();
@@ -82,11 +83,31 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
                     if ((key & mask) == prefix) atomicAdd(&hist[(key >> (pass * 8)) & 255u], 1u);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int b = 255, cum = 0;
-                    for (; b > 0; --b) { if (cum + (int)hist[b] >= remaining) break; cum += (int)hist[b]; }
-                    sh_u[0] = (unsigned)b; sh_u[1] = (unsigned)cum;
+                if (tid < 64) {   // wave 0: descending cumulative count over the 256 bins, 4 bins per lane
+                    const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                    const unsigned tot = c0 + c1 + c2 + c3;
+                    unsigned suf = tot;   // inclusive suffix sum over lanes >= tid
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned t = __shfl_down(suf, o, 64);
+                        if (tid + o < 64) suf += t;
+                    }
+                    const unsigned above = suf - tot;
+                    if (tid == 0) { sh_u[0] = 0; sh_u[1] = suf - c0; }          // fallback: bin 0
+                    if (above < (unsigned)remaining && suf >= (unsigned)remaining) {
+                        unsigned cum = above;
+                        const unsigned c[4] = {c0, c1, c2, c3};
+                        int pick = 0;
+#pragma unroll
+                        for (int b = 3; b >= 0; --b) {
+                            if (cum + c[b] >= (unsigned)remaining) { pick = b; break; }
+                            cum += c[b];
+                        }
+                        sh_u[4] = 4 * tid + pick; sh_u[5] = cum; sh_u[6] = 1;
+                    }
                 }
+                __syncthreads();
+                if (tid == 0) { if (sh_u[6]) { sh_u[0] = sh_u[4]; sh_u[1] = sh_u[5]; } sh_u[6] = 0; }
                 __syncthreads();
                 prefix |= sh_u[0] << (pass * 8);
                 mask |= 0xffu << (pass * 8);
@@ -118,6 +139,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
             if (tid < 64) {
                 // ---- bitonic sort of 64 candidates by (value desc, index asc), one per lane
                 Cand c = cand[tid];
+                if (tid >= k) { c.v = -INFINITY; c.idx = 0x7fffffff; }
                 for (int size = 2; size <= 64; size <<= 1)
                     for (int stride = size >> 1; stride > 0; stride >>= 1) {
                         Cand o; o.v = __shfl_xor(c.v, stride, 64); o.idx = __shfl_xor(c.idx, stride, 64);
@@ -129,27 +151,32 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
                 cand[tid] = c;
             }
             __syncthreads();
-            if (tid == 0) {
-                int n = 0;
-                while (n < k && n < 64 && cand[n].v > -INFINITY) ++n;     // finite candidates only
+            if (tid < 64) {
+                // wave 0 holds the sorted candidates one per lane; every sum is accumulated in candidate order
+                // (the oracle's order) by broadcasting lane j to all lanes - sequential semantics, no LDS round trips
+                const Cand c = cand[tid];
+                const unsigned long long fin = __ballot(tid < k && c.v > -INFINITY);
+                const int n = __popcll(fin);                                  // finite candidates are a prefix after the sort
                 if (n > 0) {
-                    const float mx = cand[0].v;
+                    const float mx = __shfl(c.v, 0, 64);
+                    const float p = tid < n ? expf(__fsub_rn(c.v, mx)) : 0.f;
                     float total = 0.f;
-                    for (int j = 0; j < n; ++j) { const float p = expf(__fsub_rn(cand[j].v, mx)); cand[j].v = p; total = __fadd_rn(total, p); }
+                    for (int j = 0; j < n; ++j) total = __fadd_rn(total, __shfl(p, j, 64));
                     int keep = n;
                     if (A.top_p < 1.0f) {
                         const float lim = __fmul_rn(A.top_p, total);
                         float cum = 0.f;
-                        for (int j = 0; j < n; ++j) { cum = __fadd_rn(cum, cand[j].v); if (cum >= lim) { keep = j + 1; break; } }
-                        if (keep < n || cum >= lim) total = cum;
+                        for (int j = 0; j < n; ++j) { cum = __fadd_rn(cum, __shfl(p, j, 64)); if (cum >= lim) { keep = j + 1; break; } }
+                        total = cum;
                     }
                     const float u = rt_uniform(A.seed, (unsigned)A.item_ids[row], (unsigned)A.frame, (unsigned)A.group);
                     const float target = __fmul_rn(u, total);
                     float cum = 0.f;
-                    int pick = cand[keep - 1].idx;
-                    for (int j = 0; j < keep; ++j) { cum = __fadd_rn(cum, cand[j].v); if (cum > target) { pick = cand[j].idx; break; } }
-                    sh_i[0] = pick;
-                } else {
+                    int pick_lane = keep - 1;
+                    for (int j = 0; j < keep; ++j) { cum = __fadd_rn(cum, __shfl(p, j, 64)); if (cum > target) { pick_lane = j; break; } }
+                    const int pick = __shfl(c.idx, pick_lane, 64);
+                    if (tid == 0) sh_i[0] = pick;
+                } else if (tid == 0) {
                     sh_i[0] = token;
                 }
             }
