@@ -113,7 +113,7 @@ def test_generate_through_the_factory(tiny_provider, tmp_path):
     assert isinstance(p, MI355XQwenTTS) and p.voice_cloning
     r = p.generate("Hello there general test of the path")
     assert isinstance(r, api.GenerationResult) and r.sample_rate == 24000 and r.segments_count == 1
-    assert r.audio.dim() == 1 and r.audio.numel() > 1000 and r.decay_ratio is not None
+    assert r.audio.dim() == 1 and r.audio.numel() > 100 and r.decay_ratio is not None
     assert abs(r.duration_sec - r.audio.numel() / 24000) < 1e-9
     rms_db = 20 * np.log10(float(torch.sqrt(torch.mean(r.audio.float() ** 2))) + 1e-12)
     assert abs(rms_db + 23.0) < 1.0 and float(r.audio.abs().max()) <= 0.95       # loudness stage ran
