@@ -263,6 +263,12 @@ RT_API int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t 
 RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed,
                            int32_t frame, int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out);
 
+/* Tuning knobs of the decode GEMM (negative / zero = leave unchanged) and a back-to-back launch microbenchmark that
+ * cycles over n_mats weight matrices (choose n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
+RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);
+RT_API int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t split_k, int32_t n_mats, int32_t iters,
+                                double* avg_us, int32_t* used_split);
+
 #ifdef __cplusplus
 }
 #endif

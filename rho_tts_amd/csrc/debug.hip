@@ -86,4 +86,45 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
     return rc;
 }
 
+int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 0) g_skinny_variant = skinny_variant;
+    if (skinny_waves_per_cu > 0) g_skinny_waves_per_cu = skinny_waves_per_cu;
+    return RT_OK;
+}
+
+int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t split_k, int32_t n_mats, int32_t iters, double* avg_us,
+                         int32_t* used_split) {
+    if (!ctx || !avg_us || M < 1 || M > 64 || N < 32 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_skinny: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pb = packed_bytes(N, K);
+    bf16_t* wbuf = nullptr;
+    bf16_t* a = nullptr;
+    float* out = nullptr;
+    if (split_k < 1) split_k = skinny_pick_split(M, N, K, ctx->n_cu);
+    if (used_split) *used_split = split_k;
+    RT_HIP(ctx, hipMalloc((void**)&wbuf, pb * n_mats));
+    RT_HIP(ctx, hipMalloc((void**)&a, (size_t)M * K * 2));
+    RT_HIP(ctx, hipMalloc((void**)&out, (size_t)split_k * M * N * 4));
+    RT_HIP(ctx, hipMemsetAsync(wbuf, 0x3c, pb * n_mats, ctx->stream));     // bf16 0x3c3c = 0.0115: non-zero operands
+    RT_HIP(ctx, hipMemsetAsync(a, 0x3c, (size_t)M * K * 2, ctx->stream));
+    PackedW pw;
+    pw.N = N; pw.K = K; pw.Np = (N + 31) / 32 * 32; pw.Kp = K;
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    int rc = RT_OK;
+    for (int i = 0; i < n_mats && !rc; ++i) { pw.data = wbuf + (pb / 2) * i; rc = launch_gemm_skinny(ctx, a, M, pw, out, N, split_k); }
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters && !rc; ++i) { pw.data = wbuf + (pb / 2) * (i % n_mats); rc = launch_gemm_skinny(ctx, a, M, pw, out, N, split_k); }
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(wbuf); (void)hipFree(a); (void)hipFree(out);
+    return rc;
+}
+
 }  // extern "C"

@@ -110,6 +110,85 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t* __restrict__ 
     }
 }
 
+// Variant 2 of the decode GEMM: the workgroup's four waves share one K-slice, so the activation slab
+// A[M][k0:k1] is staged ONCE per workgroup into LDS with fully coalesced 16-B loads (instead of four waves each
+// issuing row-strided fragment loads), and the weight stream is software-pipelined: the 1-KiB B loads of step i+1
+// are in flight while step i's MFMAs run.  LDS rows are padded by 16 B so the 32-row x 16-B fragment reads of a
+// ds_read_b128 spread over all banks.
+template <int MT, int U>
+__global__ __launch_bounds__(256) void k_gemm_skinny2(const bf16_t* __restrict__ A, int M, int K, const bf16_t* __restrict__ Wp,
+                                                      int NT, int KT, int kt_per_split, float* __restrict__ out, int64_t ldc,
+                                                      int N) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_a[];   // [MT*32][ks*2 + 16] bytes
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nt = blockIdx.x * 4 + w;
+    const int r = lane & 31, h = lane >> 5;
+    const int kt0 = blockIdx.y * kt_per_split;
+    int kt1 = kt0 + kt_per_split;
+    if (kt1 > KT) kt1 = KT;
+    const int n_k = kt1 - kt0;
+    const int ks = n_k * 16;                    // k elements of this slice
+    const int row_bytes = ks * 2 + 16;
+    // ---- stage A: rows x ks bf16, 16-B pieces, coalesced along k
+    {
+        const int pieces_per_row = ks / 8;
+        const int total = MT * 32 * pieces_per_row;
+        for (int p = threadIdx.x; p < total; p += 256) {
+            const int row = p / pieces_per_row, pc = p - row * pieces_per_row;
+            const int src_row = row < M ? row : M - 1;
+            const s8_t v = *reinterpret_cast<const s8_t*>(A + (int64_t)src_row * K + kt0 * 16 + pc * 8);
+            *reinterpret_cast<s8_t*>(lds_a + row * row_bytes + pc * 16) = v;
+        }
+    }
+    __syncthreads();
+    if (nt >= NT) return;
+    const s8_t* wp = reinterpret_cast<const s8_t*>(Wp) + ((int64_t)nt * KT + kt0) * 64 + lane;
+    f16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+    const unsigned char* abase = lds_a + r * row_bytes + h * 16;
+
+    s8_t b_cur[U], b_nxt[U];
+    int kt = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) b_cur[u] = (u < n_k) ? __builtin_nontemporal_load(wp + (int64_t)u * 64) : s8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    for (; kt < n_k; kt += U) {
+        const bool more = kt + U < n_k;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                b_nxt[u] = (kt + U + u < n_k) ? __builtin_nontemporal_load(wp + (int64_t)(kt + U + u) * 64) : s8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (kt + u < n_k) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const s8_t a = *reinterpret_cast<const s8_t*>(abase + (mt * 32) * row_bytes + (kt + u) * 32);
+                    acc[mt] = mfma32(a, b_cur[u], acc[mt]);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) b_cur[u] = b_nxt[u];
+        }
+    }
+    float* o = out + (int64_t)blockIdx.y * M * ldc;
+    const int n = nt * 32 + r;
+    if (n < N) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row < M) o[(int64_t)row * ldc + n] = acc[mt][i];
+            }
+    }
+}
+
 // ----------------------------------------------------------------------------------------- tiled
 constexpr int BM = 128, BN = 128, BK = 32;
 
@@ -339,11 +418,14 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
     return RT_OK;
 }
 
+int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
+int g_skinny_waves_per_cu = 4;  // split-K is chosen so that about this many waves per CU stream weights
+
 int skinny_pick_split(int M, int N, int K, int n_cu) {
     const int tiles = (N + 31) / 32, KT = (K + 15) / 16;
-    const int target = n_cu * 4;  // one wave per SIMD
+    const int target = n_cu * g_skinny_waves_per_cu;
     int s = 1;
-    while (s < 16 && tiles * (s * 2) <= target && KT % (s * 2) == 0 && KT / (s * 2) >= 8) s *= 2;
+    while (s < 32 && tiles * (s * 2) <= target && KT % (s * 2) == 0 && KT / (s * 2) >= 4) s *= 2;
     return s;
 }
 
@@ -354,6 +436,21 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
     const int NT = w.Np / 32, KT = w.Kp / 16;
     if (split_k < 1 || KT % split_k) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: split_k=%d does not divide %d k-tiles", split_k, KT);
     dim3 grid((NT + 3) / 4, split_k);
+    if (g_skinny_variant > 0) {
+        const int mt = M <= 32 ? 1 : 2;
+        const size_t lds = (size_t)mt * 32 * ((KT / split_k) * 32 + 16);
+        if (lds <= 64 * 1024) {
+            if (g_skinny_variant == 1) {
+                if (mt == 1) hipExtLaunchKernelGGL((k_gemm_skinny2<1, 4>), grid, dim3(256), lds, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+                else hipExtLaunchKernelGGL((k_gemm_skinny2<2, 4>), grid, dim3(256), lds, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+            } else {
+                if (mt == 1) hipExtLaunchKernelGGL((k_gemm_skinny2<1, 8>), grid, dim3(256), lds, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+                else hipExtLaunchKernelGGL((k_gemm_skinny2<2, 8>), grid, dim3(256), lds, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+            }
+            RT_HIP(ctx, hipGetLastError());
+            return RT_OK;
+        }
+    }
     // hipExtLaunchKernelGGL stamps the events at the kernel's own begin/end on the device (no launch gaps inside)
     if (M <= 32)
         hipExtLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,

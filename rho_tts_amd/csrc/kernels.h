@@ -60,6 +60,8 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int skinny_pick_split(int M, int N, int K, int n_cu);
+extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
+extern int g_skinny_waves_per_cu;
 
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
