@@ -10,15 +10,21 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 
-template <int D, int REP>
+// FUSED (decode rows only, one row per sequence slot): `q` is the raw qkv projection [M][(heads+2kv)*D]; the workgroup
+// first finishes its own head group - RMSNorm over the head, rotate-half RoPE, K/V rounded to bf16 and appended to
+// the cache row (slot, pos) - then attends over the cache including the row it has just written.
+template <int D, int REP, bool FUSED>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, int heads, int kv_heads,
                                                    const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
-                                                   int pos_add, int window, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
-                                                   int max_pos, bf16_t* __restrict__ out) {
+                                                   int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                   int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
+                                                   const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
+                                                   const float* __restrict__ sinT) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
     __shared__ float sh[4][REP][LPP][10];
+    __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
 
     const int row = blockIdx.x, kh = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -29,12 +35,49 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     const int slot = row_slot[row];
     const float scale = rsqrtf((float)D);
 
+    if (FUSED) {
+        // vectors of this head group: REP query heads, then K, then V; wave w takes vectors w, w+4, ...
+        constexpr int half = D / 2;
+        const int width = (heads + 2 * kv_heads) * D;
+        for (int vec = w; vec < REP + 2; vec += 4) {
+            const bool is_q = vec < REP, is_k = vec == REP;
+            const int col0 = is_q ? (kh * REP + vec) * D : (is_k ? (heads + kh) * D : (heads + kv_heads + kh) * D);
+            const bool act = lane < half;
+            float a = 0.f, b = 0.f;
+            if (act) { a = q[(int64_t)row * width + col0 + lane]; b = q[(int64_t)row * width + col0 + lane + half]; }
+            if (is_q || is_k) {
+                const float* nw = is_q ? qw : kw;
+                if (nw) {
+                    const float ss = wave_sum_f32(act ? a * a + b * b : 0.f);
+                    const float inv = rsqrtf(ss / (float)D + eps);
+                    if (act) { a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv); }
+                }
+                if (act) {
+                    const float c = cosT[(int64_t)hi * half + lane], s = sinT[(int64_t)hi * half + lane];
+                    const float ra = a * c - b * s, rb = b * c + a * s;
+                    a = ra; b = rb;
+                }
+            }
+            if (act) {
+                if (is_q) { sh_q[FUSED ? vec : 0][FUSED ? lane : 0] = a; sh_q[FUSED ? vec : 0][FUSED ? lane + half : 0] = b; }
+                else {
+                    bf16_t* o = (is_k ? kc : vc) + (((int64_t)slot * kv_heads + kh) * max_pos + hi) * D;
+                    o[lane] = f32_to_bf16(a);
+                    o[lane + half] = f32_to_bf16(b);
+                }
+            }
+        }
+        __syncthreads();   // K/V row visible to the whole workgroup (same CU), q in LDS
+    }
+
     float qr[REP][8];
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
-        const float* qp = q + ((int64_t)row * heads + kh * REP + r) * D + sub * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qr[r][j] = qp[j] * scale;
+        for (int j = 0; j < 8; ++j) {
+            if (FUSED) qr[r][j] = sh_q[FUSED ? r : 0][FUSED ? sub * 8 + j : 0] * scale;
+            else qr[r][j] = q[((int64_t)row * heads + kh * REP + r) * D + sub * 8 + j] * scale;
+        }
     }
     float m[REP], l[REP], acc[REP][8];
 #pragma unroll
@@ -124,33 +167,48 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     }
 }
 
-template <int D>
+struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; };
+
+template <int D, bool FUSED>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
-                 int pos_add, int window, const bf16_t* kc, const bf16_t* vc, int max_pos, bf16_t* out) {
+                 int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 
+template <bool FUSED>
+int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot, const int32_t* row_pos,
+                  int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const FusedArgs& f) {
+    if (M <= 0) return RT_OK;
+    if (heads % kv_heads) return rt_fail(ctx, RT_ERR_INVALID, "attention: heads %d not a multiple of kv_heads %d", heads, kv_heads);
+    const int rep = heads / kv_heads;
+    bf16_t* kc = kv.k + layer * kv.layer_stride();
+    bf16_t* vc = kv.v + layer * kv.layer_stride();
+    dim3 grid(M, kv_heads);
+    switch (head_dim) {
+        case 32: return dispatch_rep<32, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+        case 64: return dispatch_rep<64, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+        case 128: return dispatch_rep<128, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+        default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32, 64, 128)", head_dim);
+    }
+}
+
 }  // namespace
 
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
                      const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out) {
-    if (M <= 0) return RT_OK;
-    if (heads % kv_heads) return rt_fail(ctx, RT_ERR_INVALID, "attention: heads %d not a multiple of kv_heads %d", heads, kv_heads);
-    const int rep = heads / kv_heads;
-    const bf16_t* kc = kv.k + layer * kv.layer_stride();
-    const bf16_t* vc = kv.v + layer * kv.layer_stride();
-    dim3 grid(M, kv_heads);
-    switch (head_dim) {
-        case 32: return dispatch_rep<32>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
-        case 64: return dispatch_rep<64>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
-        case 128: return dispatch_rep<128>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out);
-        default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32, 64, 128)", head_dim);
-    }
+    return attention_any<false>(ctx, q, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, FusedArgs{});
+}
+
+int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
+                           const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
+                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out) {
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps};
+    return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

@@ -418,6 +418,7 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
     return RT_OK;
 }
 
+int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
 int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
 int g_skinny_waves_per_cu = 4;  // split-K is chosen so that about this many waves per CU stream weights
 

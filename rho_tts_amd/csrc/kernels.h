@@ -60,8 +60,35 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int skinny_pick_split(int M, int N, int K, int n_cu);
+extern int g_decode_col;
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
 extern int g_skinny_waves_per_cu;
+
+// Column-owner decode GEMM (gemm_col.hip): whole-K per workgroup, fused RMSNorm prologue and residual / SwiGLU epilogues.
+enum { COL_STORE = 0, COL_RESID = 1, COL_SILU = 2 };
+struct ColArgs {
+    const void* A = nullptr;        // bf16 [M][K], or the f32 residual stream [M][K] when a_norm
+    int a_norm = 0;                 // 1: A is f32; apply rsqrt(sum(rowsq)/K + eps) * norm_w while loading
+    const float* rowsq = nullptr;   // [M][rowsq_n] partial sums of squares of A's rows
+    int rowsq_n = 0;
+    float eps = 0.f;
+    const float* norm_w = nullptr;  // [K]
+    int M = 0, K = 0;
+    int epi = COL_STORE;
+    float* out = nullptr;           // STORE: out [M][ldc] f32;  RESID: residual stream, updated in place
+    int64_t ldc = 0;
+    const float* bias = nullptr;    // [N] optional
+    const float* scale = nullptr;   // [N] optional (layer scale), RESID only
+    float* rowsq_out = nullptr;     // RESID: [M][rowsq_out_n] sums of squares of the new x per 32-column tile
+    int rowsq_out_n = 0;
+    bf16_t* out_bf16 = nullptr;     // SILU: act [M][ldc]
+    // filled by the launcher
+    const bf16_t* Wp = nullptr;
+    int NT = 0, KT = 0, N = 0, up_tile_offset = 0;
+};
+int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)
+int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n);
 
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
@@ -88,6 +115,11 @@ int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int hea
 // o[M][heads*d] (bf16) = softmax(q k^T / sqrt(d)) v over cache rows [max(0,pos-window+1), pos] of the row's slot
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
                      const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out);
+
+// decode-only fusion of q/k-norm + RoPE + KV append + attention: qkv [M][(heads+2kv)*d] f32 (complete dot products)
+int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
+                           const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
+                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out);
 
 // ------------------------------------------------------------------------------ embedding kernels
 // out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.

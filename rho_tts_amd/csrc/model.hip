@@ -349,6 +349,63 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
     return RT_OK;
 }
 
+// ---- decode-time stack (M <= 64): 5 launches per layer with the column-owner GEMM and the fused attention.
+// x is the un-normalised residual stream; rowsq [M][H/32] carries the per-tile sums of squares of x that the next
+// NORM prologue turns into the RMSNorm row scale.  On return x and rowsq describe the stack's output BEFORE the final
+// norm, which the consumer (LM head / mtp projection) applies in its own prologue.
+struct DecWs {
+    float* qkv = nullptr;   // [M][(heads + 2 kv) * d]
+    bf16_t* ao = nullptr;   // [M][q_dim]
+    bf16_t* act = nullptr;  // [M][inter]
+};
+int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
+    RT_TRY(pool_arr(m, (size_t)M * (d.heads + 2 * d.kv_heads) * d.head_dim, &w->qkv));
+    RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->ao));
+    RT_TRY(pool_arr(m, (size_t)M * d.inter, &w->act));
+    return RT_OK;
+}
+int col_gemm(rt_model* m, ColArgs& a, const PackedW& W) {
+    hipEvent_t e0, e1;
+    prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
+    return launch_gemm_col(m->ctx, a, W, e0, e1);
+}
+int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
+                 int pos_add) {
+    rt_ctx* ctx = m->ctx;
+    const rt_stack_dims& d = S.d;
+    const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
+    for (int i = 0; i < d.layers; ++i) {
+        LayerW& L = S.L[i];
+        ColArgs a;
+        a.A = x; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.norm_w = L.ln1; a.M = M; a.K = H;
+        a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw;
+        RT_TRY(col_gemm(m, a, L.wqkv));
+        RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
+                                      pos_add, S.window, S.kv, i, w.ao));
+        ColArgs o;
+        o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
+        o.rowsq_out = rowsq; o.rowsq_out_n = NTh;
+        RT_TRY(col_gemm(m, o, L.wo));
+        ColArgs gu;
+        gu.A = x; gu.a_norm = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.norm_w = L.ln2; gu.M = M; gu.K = H;
+        gu.epi = COL_SILU; gu.out_bf16 = w.act; gu.ldc = d.inter;
+        RT_TRY(col_gemm(m, gu, L.wgu));
+        ColArgs dn;
+        dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
+        dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh;
+        RT_TRY(col_gemm(m, dn, L.wd));
+    }
+    return RT_OK;
+}
+// out[M][N] = rmsnorm(x) W^T (+ bias): LM heads and the mtp projection, final norm applied in the GEMM prologue
+int col_head(rt_model* m, const float* x, const float* rowsq, int rowsq_n, int M, int K, const float* norm_w, float eps, const PackedW& W,
+             const float* bias, float* out) {
+    ColArgs a;
+    a.A = x; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.norm_w = norm_w; a.M = M; a.K = K;
+    a.epi = COL_STORE; a.out = out; a.ldc = W.N; a.bias = bias;
+    return col_gemm(m, a, W);
+}
+
 // text_proj(text_embedding[ids]) -> f32 [n][H]
 int text_project(rt_model* m, const int32_t* d_ids, int n, float* out) {
     rt_ctx* ctx = m->ctx;
@@ -788,11 +845,26 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(pool_arr(m, forced_host.size(), &d_forced));
         RT_HIP(ctx, hipMemcpyAsync(d_forced, forced_host.data(), forced_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    // hn <- final-norm rows of each item's last prompt position
-    RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
+    // decode state.  Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
+    const bool col = g_decode_col && B2 <= 64;
+    const int NTt = H / 32, NTp = Hp / 32;
+    float *rowsq_t = nullptr, *rowsq_p = nullptr, *x_all = x;
+    DecWs dwt, dwp;
     StackWs wt, wp;
-    RT_TRY(alloc_stack_ws(m, c.talker, B, &wt));
-    RT_TRY(alloc_stack_ws(m, c.predictor, B2, &wp));
+    if (col) {
+        RT_TRY(pool_arr(m, (size_t)B * NTt, &rowsq_t));
+        RT_TRY(pool_arr(m, (size_t)B2 * NTp, &rowsq_p));
+        RT_TRY(alloc_dec_ws(m, c.talker, B, &dwt));
+        RT_TRY(alloc_dec_ws(m, c.predictor, B2, &dwp));
+        // xt <- residual-stream rows (before the final norm) of each item's last prompt position
+        RT_TRY(launch_gather_f32(ctx, x_all, H, d_last, B, xt, nullptr));
+        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
+    } else {
+        // hn <- final-norm rows of each item's last prompt position
+        RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
+        RT_TRY(alloc_stack_ws(m, c.talker, B, &wt));
+        RT_TRY(alloc_stack_ws(m, c.predictor, B2, &wp));
+    }
     const PackedW& head = PW(m, "talker.codec_head");
 
     std::vector<int32_t> eos_host((size_t)T_max * B, 0);
@@ -805,7 +877,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         int32_t* codes_t = d_codes + (size_t)t * B * G;
         int ns = 0;
         // ---- group 0 from the talker state
-        RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
+        if (col) { RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
+        else RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
         SampleArgs sa{};
         sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
         sa.do_sample = A->talker.do_sample; sa.temperature = A->talker.temperature; sa.top_k = A->talker.top_k; sa.top_p = A->talker.top_p;
@@ -819,21 +892,36 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(launch_sample(ctx, sa));
         // ---- predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
-            RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
-            RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
+            if (col) RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
+            else {
+                RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
+                RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
+            }
         }
         // (index extraction) codes_t has stride G; build a dense index vector with a tiny strided copy
         RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
         if (m->has_mtp()) {
             RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_tmp_idx, B, xp + (size_t)B * Hp, nullptr));
         } else {
-            RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            if (col) RT_TRY(launch_add_rmsnorm(ctx, xt, B, H, nullptr, 0, nullptr, nullptr, m->talker.norm, c.talker.rms_eps, nullptr, xp));
+            else RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
             RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr));
         }
-        RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
+        if (col) {
+            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp));
+            RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B2, d_slot_b, d_pos_p2, 0));
+        } else {
+            RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
+        }
         for (int q = 0; q < G - 1; ++q) {
-            const bf16_t* hrow = (q == 0) ? hn_p + (size_t)B * Hp : hn_p;
-            RT_TRY(gemm_rows(m, hrow, B, PW(m, "pred.head" + std::to_string(q)), logits, &ns));
+            const size_t roff = (q == 0) ? (size_t)B : 0;      // the first head reads the rows of position 1
+            if (col) {
+                RT_TRY(col_head(m, xp + roff * Hp, rowsq_p + roff * NTp, NTp, B, Hp, m->pred.norm, c.predictor.rms_eps,
+                                PW(m, "pred.head" + std::to_string(q)), nullptr, logits));
+                ns = 1;
+            } else {
+                RT_TRY(gemm_rows(m, hn_p + roff * Hp, B, PW(m, "pred.head" + std::to_string(q)), logits, &ns));
+            }
             SampleArgs sp{};
             sp.logits = logits; sp.n_slabs = ns; sp.M = B; sp.V = Vp;
             sp.do_sample = A->predictor.do_sample; sp.temperature = A->predictor.temperature; sp.top_k = A->predictor.top_k;
@@ -847,7 +935,12 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t + q + 1, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
                 if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_tmp_idx, B, xp, nullptr));
                 else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp, nullptr));
-                RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
+                if (col) {
+                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp));
+                    RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
+                } else {
+                    RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
+                }
             }
         }
         frames_run = t + 1;
@@ -867,7 +960,12 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         if (all_done) break;
         // ---- next talker input: sum of the frame's G code embeddings + projected tts_pad
         RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes_t, B, H, pad_t, nullptr, nullptr, xt, nullptr));
-        RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, t, hn, hn_f32));
+        if (col) {
+            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
+            RT_TRY(stack_decode(m, m->talker, dwt, xt, rowsq_t, B, d_slot_b, d_pos_b, t));
+        } else {
+            RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, t, hn, hn_f32));
+        }
     }
     // ---- results
     std::vector<int32_t> codes_host((size_t)std::max(frames_run, 1) * B * G);

@@ -69,6 +69,17 @@ __global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int 
     }
 }
 
+// rowsq[row][0] = sum x^2, rowsq[row][1..n) = 0: seeds the NORM prologue of the column-owner GEMM.
+__global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int H, float* __restrict__ rowsq, int rowsq_n) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const f4_t* xr = reinterpret_cast<const f4_t*>(x + row * H);
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < (H >> 2); i += 256) { const f4_t v = xr[i]; ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    const float tot = block_sum_f32(ss, sh);
+    for (int j = threadIdx.x; j < rowsq_n; j += 256) rowsq[row * rowsq_n + j] = j == 0 ? tot : 0.f;
+}
+
 __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
                            int64_t total4) {
     const int I4 = I >> 2;
@@ -280,6 +291,13 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
     if (H % 4 || H > 8192) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rmsnorm: hidden size %d unsupported (multiple of 4, <= 8192)", H);
     hipLaunchKernelGGL(k_add_rmsnorm, dim3(M), dim3(256), 0, ctx->stream, x, H, slabs, n_slabs, (int64_t)M * H, slab_bias, scale, w,
                        eps, out_bf16, out_f32);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n) {
+    if (M <= 0) return RT_OK;
+    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -165,3 +165,25 @@ def test_code2wav_rmse(models):
     # transposed convs' one-step look-ahead, which the length trim removes)
     solo = nm.code2wav([codes[0]])[0]
     assert torch.equal(solo, wavs[0])
+
+
+def test_legacy_and_column_decode_paths_agree(models):
+    """The 9-launch split-K decode path (used when 2B > 64) and the 5-launch column-owner path compute the same logits."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    v = make_voice(cfg, True)
+    set_voice(nm, v)
+    free = om.generate(v, TEXTS, FRAMES, SamplingParams())
+    lib = nm.lib
+    try:
+        lib.rt_debug_tune(100, 0)                                   # legacy
+        _, tr_a = nm.generate(TEXTS, FRAMES, RtSampling(0, 1, 1, 1, 1), forced_codes=free, trace=True)
+    finally:
+        lib.rt_debug_tune(101, 0)                                   # column path (default)
+    _, tr_b = nm.generate(TEXTS, FRAMES, RtSampling(0, 1, 1, 1, 1), forced_codes=free, trace=True)
+    V0 = cfg.codec.codebook_size
+    for key in ("talker", "predictor"):
+        a, b = tr_a[key].cpu(), tr_b[key].cpu()
+        if key == "talker":
+            a, b = a[..., :V0], b[..., :V0]
+        assert float((a - b).abs().max()) <= 0.02 * float(a.std()) + 1e-6
