@@ -28,13 +28,14 @@ __device__ __forceinline__ f16_t mfma32(s8_t a, s8_t b, f16_t c) {
 }
 __device__ __forceinline__ unsigned pk2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
 
-constexpr int WAVES = 8;
+constexpr int WAVES = 16;   // 1024 threads: 4 waves per SIMD, every one with its own weight run in flight
 
 template <int MT, bool NORM, int EPI>
-__global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
-    __shared__ float red[WAVES][16][64];   // 32 KiB: one accumulator tile per wave
+__global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
+    __shared__ float red[8][16][64];       // 32 KiB: accumulator tiles of 8 waves at a time
+    __shared__ float sh_inv[64];           // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int U = NORM ? 4 : 8;        // k-tiles in flight per wave
+    constexpr int U = NORM ? (NB == 1 ? 4 : 2) : (NB == 1 ? 8 : 4);   // k-tiles in flight per wave (128-VGPR budget, no spills)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nt = blockIdx.x;
@@ -48,6 +49,26 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
 
+    // first weight loads go out before anything else: they are the long pole
+    s8_t bw[NB][U];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = u < n_k ? u : (n_k > 0 ? n_k - 1 : 0);
+            if (n_k > 0) bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
+        }
+
+    if (NORM) {   // row scales once per workgroup: thread t sums the partials of row t
+        if (tid < MT * 32) {
+            int row = tid < g.M ? tid : g.M - 1;
+            const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
+            float s = 0.f;
+            for (int j = 0; j < g.rowsq_n; ++j) s += p[j];
+            sh_inv[tid] = rsqrtf(s / (float)g.K + g.eps);
+        }
+        __syncthreads();
+    }
     int arow[MT];
     float inv[MT];
 #pragma unroll
@@ -55,13 +76,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         int row = mt * 32 + r;
         if (row >= g.M) row = g.M - 1;   // clamp: computed on valid memory, never stored
         arow[mt] = row;
-        inv[mt] = 1.f;
-        if (NORM) {
-            float s = 0.f;
-            const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
-            for (int j = 0; j < g.rowsq_n; ++j) s += p[j];
-            inv[mt] = rsqrtf(s / (float)g.K + g.eps);
-        }
+        inv[mt] = NORM ? sh_inv[mt * 32 + r] : 1.f;
     }
 
     f16_t acc[NB][MT];
@@ -73,14 +88,15 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             for (int i = 0; i < 16; ++i) acc[b][mt][i] = 0.f;
 
     for (int kt = 0; kt < n_k; kt += U) {
-        s8_t bw[NB][U];
+        if (kt > 0) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = kt + u < n_k ? kt + u : n_k - 1;      // tail: re-load the last tile, result discarded
-                bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
-            }
+                for (int u = 0; u < U; ++u) {
+                    const int k = kt + u < n_k ? kt + u : n_k - 1;      // tail: re-load the last tile, result discarded
+                    bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
+                }
+        }
         s8_t af[MT][U];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -114,34 +130,44 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         }
     }
 
-    // ---- combine the 8 K-partials through LDS (fixed order) and run the fused epilogue, one accumulator tile at a time
+    // ---- combine the 16 K-partials through LDS in a fixed order (waves 8-15 fold into 0-7, then 8 -> 1) and run the
+    // fused epilogue, one accumulator tile at a time
     const int n = nt * 32 + (tid & 31);          // column of this thread in the reduce phase
     const int e_h = (tid >> 5) & 1;              // which half-wave -> +4 rows
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        float val[NB][2];
+        float val[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             __syncthreads();
+            if (w >= 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[b][mt][i];
+                for (int i = 0; i < 16; ++i) red[w - 8][i][lane] = acc[b][mt][i];
+            }
             __syncthreads();
+            if (w < 8) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = tid + q * 512;         // element id: i = e / 64, lane' = e % 64
-                const int i = e >> 6, l = e & 63;
+                for (int i = 0; i < 16; ++i) acc[b][mt][i] += red[w][i][lane];
+            }
+            __syncthreads();
+            if (w < 8) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[b][mt][i];
+            }
+            __syncthreads();
+            {
+                const int i = tid >> 6, l = tid & 63;     // 1024 threads = 16 x 64 elements of the 32x32 tile
                 float s = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < WAVES; ++ww) s += red[ww][i][l];
-                val[b][q] = s;
+                for (int ww = 0; ww < 8; ++ww) s += red[ww][i][l];
+                val[b] = s;
             }
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = (tid + q * 512) >> 6;
+        {
+            const int i = tid >> 6;
             const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * e_h;
             const bool ok = row < g.M && n < g.N;
-            float v = val[0][q];
+            float v = val[0];
             if (EPI == COL_STORE) {
                 if (ok) {
                     if (g.bias) v += g.bias[n];
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
                 if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)row * g.rowsq_out_n + nt] = sq;
             } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
                 if (ok) {
-                    const float u = val[NB - 1][q];
+                    const float u = val[NB - 1];
                     g.out_bf16[(int64_t)row * g.ldc + n] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
                 }
             }
@@ -173,9 +199,9 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
 template <int MT, bool NORM>
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     switch (g.epi) {
-        case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
         default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -185,7 +211,7 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 }  // namespace
 
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (a.M < 1 || a.M > 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..64", a.M);
+    if (a.M < 1 || a.M > 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..32 (callers split larger row blocks)", a.M);
     if (w.K != w.Kp || w.K != a.K) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: K mismatch (%d vs %d) or not a multiple of 16", w.K, a.K);
     ColArgs g = a;
     g.Wp = w.data;
@@ -203,6 +229,5 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
     if (g.epi == COL_RESID && (!g.rowsq_out || g.rowsq_out_n < g.NT)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: rowsq_out too small");
     if (g.a_norm && (!g.rowsq || !g.norm_w || g.rowsq_n < 1)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: norm prologue without partials");
     dim3 grid(tiles);
-    if (g.M <= 32) return g.a_norm ? dispatch_epi<1, true>(ctx, g, grid, ev_start, ev_stop) : dispatch_epi<1, false>(ctx, g, grid, ev_start, ev_stop);
-    return g.a_norm ? dispatch_epi<2, true>(ctx, g, grid, ev_start, ev_stop) : dispatch_epi<2, false>(ctx, g, grid, ev_start, ev_stop);
+    return g.a_norm ? dispatch_epi<1, true>(ctx, g, grid, ev_start, ev_stop) : dispatch_epi<1, false>(ctx, g, grid, ev_start, ev_stop);
 }

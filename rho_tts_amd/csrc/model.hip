@@ -357,20 +357,36 @@ struct DecWs {
     float* qkv = nullptr;   // [M][(heads + 2 kv) * d]
     bf16_t* ao = nullptr;   // [M][q_dim]
     bf16_t* act = nullptr;  // [M][inter]
+    float* q = nullptr;     // [M][q_dim] (only for passes with several rows per slot)
 };
 int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
+    RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
     RT_TRY(pool_arr(m, (size_t)M * (d.heads + 2 * d.kv_heads) * d.head_dim, &w->qkv));
     RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->ao));
     RT_TRY(pool_arr(m, (size_t)M * d.inter, &w->act));
     return RT_OK;
 }
-int col_gemm(rt_model* m, ColArgs& a, const PackedW& W) {
-    hipEvent_t e0, e1;
-    prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
-    return launch_gemm_col(m->ctx, a, W, e0, e1);
+// Row blocks of 32: a 64-row pass (the predictor's first, 2 rows per sequence) streams the weights twice.
+int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W) {
+    for (int r0 = 0; r0 < a0.M; r0 += 32) {
+        ColArgs a = a0;
+        a.M = std::min(32, a0.M - r0);
+        const size_t a_el = a0.a_norm ? 4 : 2;
+        a.A = (const char*)a0.A + (size_t)r0 * a0.K * a_el;
+        if (a0.rowsq) a.rowsq = a0.rowsq + (size_t)r0 * a0.rowsq_n;
+        if (a0.out) a.out = a0.out + (size_t)r0 * a0.ldc;
+        if (a0.out_bf16) a.out_bf16 = a0.out_bf16 + (size_t)r0 * a0.ldc;
+        if (a0.rowsq_out) a.rowsq_out = a0.rowsq_out + (size_t)r0 * a0.rowsq_out_n;
+        hipEvent_t e0, e1;
+        prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
+        RT_TRY(launch_gemm_col(m->ctx, a, W, e0, e1));
+    }
+    return RT_OK;
 }
+// one_row_per_slot = false (the predictor's 2-row first pass): a row must see the K/V another row of the same launch
+// appends, so q/k-norm + RoPE + append run as their own launch before the attention.
 int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
-                 int pos_add) {
+                 int pos_add, bool one_row_per_slot = true) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
@@ -380,8 +396,14 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         a.A = x; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.norm_w = L.ln1; a.M = M; a.K = H;
         a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw;
         RT_TRY(col_gemm(m, a, L.wqkv));
-        RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                                      pos_add, S.window, S.kv, i, w.ao));
+        if (one_row_per_slot) {
+            RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
+                                          pos_add, S.window, S.kv, i, w.ao));
+        } else {
+            RT_TRY(launch_qkv_post(ctx, w.qkv, 1, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
+                                   pos_add, w.q, S.kv, i));
+            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao));
+        }
         ColArgs o;
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
         o.rowsq_out = rowsq; o.rowsq_out_n = NTh;
@@ -909,7 +931,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         }
         if (col) {
             RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp));
-            RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B2, d_slot_b, d_pos_p2, 0));
+            RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B2, d_slot_b, d_pos_p2, 0, false));
         } else {
             RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
         }
