@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--tune", default="", help="comma-separated rt_debug_tune codes (100/101 legacy/column decode, 200/201 eager/graph)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,6 +93,8 @@ def main():
     eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=local_rank, max_batch=args.batch)
     if args.greedy:
         eng.params.do_sample = False
+    for code in [c for c in args.tune.split(",") if c]:
+        eng.ctx.lib.rt_debug_tune(int(code), 0)
     B = args.batch
     texts = sentences(B, args.words, seed=789 + rank)
     item_ids = list(range(rank * B, (rank + 1) * B))

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
                                                    int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                    int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
-                                                   const float* __restrict__ sinT) {
+                                                   const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     const int row = blockIdx.x, kh = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane % LPP, pg = lane / LPP;
-    const int hi = row_pos[row] + pos_add;
+    const int hi = row_pos[row] + pos_add + (frame_ptr ? *frame_ptr : 0);
     int lo = 0;
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
     const int slot = row_slot[row];
@@ -167,15 +167,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     }
 }
 
-struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; };
+struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; };
 
 template <int D, bool FUSED>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -202,13 +202,16 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
 }  // namespace
 
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
-                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out) {
-    return attention_any<false>(ctx, q, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, FusedArgs{});
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr) {
+    FusedArgs f{};
+    f.frame_ptr = frame_ptr;
+    return attention_any<false>(ctx, q, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }
 
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
-                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out) {
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps};
+                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
+                           const int32_t* frame_ptr) {
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

@@ -4,6 +4,10 @@
 #include "kernels.h"
 
 namespace {
+__global__ void k_touch(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = p[i] * 1.0001f + 1.0f;
+}
 __global__ void k_iota64(int64_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -80,6 +84,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
     a.do_sample = sp->do_sample; a.temperature = sp->temperature; a.top_k = sp->top_k; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
     a.seen = d_seen; a.suppress_from = suppress_from; a.allow_token = allow_token; a.seed = seed; a.item_ids = items; a.frame = frame; a.group = group;
     a.forced = nullptr; a.out = d_out; a.out_stride = 1; a.eos_token = -1; a.eos_flag = nullptr; a.logits_copy = nullptr;
+    a.frame_ptr = nullptr; a.seed_ptr = nullptr;
     int rc = launch_sample(ctx, a);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(items);
@@ -87,6 +92,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 200) { g_use_graph = skinny_variant - 200; return RT_OK; }            // 200: eager frames, 201: graph replay
     if (skinny_variant >= 100) { g_decode_col = skinny_variant - 100; return RT_OK; }   // 100: legacy 9-launch decode, 101: column path
     if (skinny_variant >= 0) g_skinny_variant = skinny_variant;
     if (skinny_waves_per_cu > 0) g_skinny_waves_per_cu = skinny_waves_per_cu;
@@ -126,6 +132,49 @@ int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t s
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(wbuf); (void)hipFree(a); (void)hipFree(out);
     return rc;
+}
+
+// Launch-floor microbenchmark: n dependent launches of a trivial kernel (grid_wgs x 256 threads), eagerly or as one
+// captured hipGraph replayed `reps` times.  Returns microseconds per launch.
+int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use_graph, int32_t reps, double* us_per_launch) {
+    if (!ctx || !us_per_launch || grid_wgs < 1 || n < 1 || reps < 1) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    float* buf = nullptr;
+    const int elems = grid_wgs * 256;
+    RT_HIP(ctx, hipMalloc((void**)&buf, (size_t)elems * 4));
+    RT_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)elems * 4, ctx->stream));
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        RT_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_touch, dim3(grid_wgs), dim3(256), 0, ctx->stream, buf, elems);
+        RT_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
+        RT_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        RT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_touch, dim3(grid_wgs), dim3(256), 0, ctx->stream, buf, elems);
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int rpt = 0; rpt < reps; ++rpt) {
+        if (use_graph) RT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+        else for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_touch, dim3(grid_wgs), dim3(256), 0, ctx->stream, buf, elems);
+    }
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *us_per_launch = (double)ms * 1e3 / ((double)n * reps);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -418,6 +418,7 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
     return RT_OK;
 }
 
+int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
 int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
 int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
 int g_skinny_waves_per_cu = 4;  // split-K is chosen so that about this many waves per CU stream weights
@@ -437,7 +438,7 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
     const int NT = w.Np / 32, KT = w.Kp / 16;
     if (split_k < 1 || KT % split_k) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: split_k=%d does not divide %d k-tiles", split_k, KT);
     dim3 grid((NT + 3) / 4, split_k);
-    if (g_skinny_variant > 0) {
+    if (g_skinny_variant > 0 && (ev_start || ev_stop)) {
         const int mt = M <= 32 ? 1 : 2;
         const size_t lds = (size_t)mt * 32 * ((KT / split_k) * 32 + 16);
         if (lds <= 64 * 1024) {
@@ -453,7 +454,10 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
         }
     }
     // hipExtLaunchKernelGGL stamps the events at the kernel's own begin/end on the device (no launch gaps inside)
-    if (M <= 32)
+    if (!ev_start && !ev_stop) {
+        if (M <= 32) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+        else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+    } else if (M <= 32)
         hipExtLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
                               KT / split_k, d_out, ldc, w.N);
     else

@@ -59,13 +59,16 @@ __global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
             if (n_k > 0) bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
         }
 
-    if (NORM) {   // row scales once per workgroup: thread t sums the partials of row t
-        if (tid < MT * 32) {
-            int row = tid < g.M ? tid : g.M - 1;
+    if (NORM) {   // row scales once per workgroup: half-wave (w, h) owns row 2w + h, its 32 lanes split the partials
+        const int row_i = 2 * w + h;
+        if (row_i < MT * 32) {
+            const int row = row_i < g.M ? row_i : g.M - 1;
             const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
             float s = 0.f;
-            for (int j = 0; j < g.rowsq_n; ++j) s += p[j];
-            sh_inv[tid] = rsqrtf(s / (float)g.K + g.eps);
+            for (int j = r; j < g.rowsq_n; j += 32) s += p[j];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
         }
         __syncthreads();
     }
@@ -198,6 +201,16 @@ __global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
 
 template <int MT, bool NORM>
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
+    if (!e0 && !e1) {   // plain launches are what a stream capture records
+        switch (g.epi) {
+            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(1024), 0, ctx->stream, g); break;
+            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(1024), 0, ctx->stream, g); break;
+            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(1024), 0, ctx->stream, g); break;
+            default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
+        }
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    }
     switch (g.epi) {
         case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
         case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;

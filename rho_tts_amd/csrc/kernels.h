@@ -61,6 +61,7 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int skinny_pick_split(int M, int N, int K, int n_cu);
 extern int g_decode_col;
+extern int g_use_graph;
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
 extern int g_skinny_waves_per_cu;
 
@@ -111,15 +112,20 @@ struct KvCache {
 // qkv slabs [S][M][(heads+2*kv_heads)*d] -> q (f32 [M][heads][d], normed + roped), k/v appended to the cache
 int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int heads, int kv_heads, int head_dim,
                     const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin,
-                    const int32_t* row_slot, const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer);
+                    const int32_t* row_slot, const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer,
+                    const int32_t* frame_ptr = nullptr);
 // o[M][heads*d] (bf16) = softmax(q k^T / sqrt(d)) v over cache rows [max(0,pos-window+1), pos] of the row's slot
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
-                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out);
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
+                     const int32_t* frame_ptr = nullptr);
 
+// Every launch that depends on the frame index takes `frame_ptr` (device int, nullptr = 0): positions are
+// row_pos + pos_add + *frame_ptr, so one captured hipGraph serves every frame of the decode loop.
 // decode-only fusion of q/k-norm + RoPE + KV append + attention: qkv [M][(heads+2kv)*d] f32 (complete dot products)
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
-                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out);
+                           const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
+                           const int32_t* frame_ptr = nullptr);
 
 // ------------------------------------------------------------------------------ embedding kernels
 // out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.
@@ -127,9 +133,12 @@ struct GatherSrc {
     const bf16_t* table;
     int64_t row_stride;  // elements
 };
+// idx_stride: elements between the index rows of consecutive output rows (default n_src); idx_frame_stride: added per frame.
 int launch_gather_sum(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const int32_t* d_idx, int M, int H,
-                      const float* add_vec, const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16);
-int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16);
+                      const float* add_vec, const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16,
+                      int idx_stride = 0, const int32_t* frame_ptr = nullptr, int64_t idx_frame_stride = 0);
+int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16,
+                      int idx_stride = 1, const int32_t* frame_ptr = nullptr, int64_t idx_frame_stride = 0);
 
 // ------------------------------------------------------------------------------------- sampling
 struct SampleArgs {
@@ -145,6 +154,7 @@ struct SampleArgs {
     int suppress_from;         // tokens >= suppress_from are forbidden ...
     int allow_token;           // ... except this one (-1: none)
     uint64_t seed;
+    const uint64_t* seed_ptr;  // when set, the seed is read from the device (keeps captured graphs seed-independent)
     const int64_t* item_ids;   // [M]
     int frame, group;
     const int32_t* forced;     // [M] or null: teacher forcing (value < 0 = not forced)
@@ -153,6 +163,11 @@ struct SampleArgs {
     int eos_token;             // >= 0: a drawn eos is reported in eos_flag[r] and replaced by 0 in `out`
     int32_t* eos_flag;         // [M] or null
     float* logits_copy;        // optional [M][V] summed logits for tracing
+    // frame-indexed addressing for graph replay: when frame_ptr != nullptr the frame index is read from the device and
+    // out / eos_flag / forced / logits_copy are advanced by frame * their stride; eos is allowed from min_frames on
+    const int32_t* frame_ptr;
+    int64_t out_fs, eos_fs, forced_fs, copy_fs;
+    int eos_live, min_frames;
 };
 int launch_sample(rt_ctx* ctx, const SampleArgs& a);
 

@@ -75,6 +75,7 @@ __global__ void k_add_vec(float* __restrict__ dst, const float* __restrict__ src
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
 }
+__global__ void k_frame_inc(int32_t* f) { if (threadIdx.x == 0) *f += 1; }
 __global__ void k_fill_i32(int32_t* p, int n, int v, int step_every, int step) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v + (step_every > 0 ? (i / step_every) * step : 0);
 }
@@ -106,6 +107,10 @@ struct rt_model {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     size_t prof_used = 0;
     double prof_bytes = 0;
+    // decode-frame graphs (A: LM head + sample + residual-code predictor, B: next input + talker step), reused while the
+    // launch signature (every pointer and parameter baked into the nodes) stays the same
+    uint64_t graph_sig = 0;
+    hipGraphExec_t graph_a = nullptr, graph_b = nullptr;
     int64_t weight_bytes = 0;
 
     bool has_mtp() const { return cfg.talker.hidden != cfg.predictor.hidden; }
@@ -325,7 +330,7 @@ int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w) {
 
 // x [M][H] f32 in/out (residual stream); on return out_bf16/out_f32 hold the final-norm output.
 int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
-                  bf16_t* out_bf16, float* out_f32) {
+                  bf16_t* out_bf16, float* out_f32, const int32_t* frame_ptr = nullptr) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden;
@@ -336,8 +341,8 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
         RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, L.ln1, d.rms_eps, w.xn, nullptr));
         RT_TRY(gemm_rows(m, w.xn, M, L.wqkv, w.slabs, &ns));
         RT_TRY(launch_qkv_post(ctx, w.slabs, ns, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                               pos_add, w.q, S.kv, i));
-        RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao));
+                               pos_add, w.q, S.kv, i, frame_ptr));
+        RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr));
         RT_TRY(gemm_rows(m, w.ao, M, L.wo, w.slabs, &ns));
         RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, L.ls1, L.ln2, d.rms_eps, w.xn, nullptr));
         RT_TRY(gemm_rows(m, w.xn, M, L.wgu, w.slabs, &ns));
@@ -386,7 +391,7 @@ int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W) {
 // one_row_per_slot = false (the predictor's 2-row first pass): a row must see the K/V another row of the same launch
 // appends, so q/k-norm + RoPE + append run as their own launch before the attention.
 int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
-                 int pos_add, bool one_row_per_slot = true) {
+                 int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
@@ -398,11 +403,11 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         RT_TRY(col_gemm(m, a, L.wqkv));
         if (one_row_per_slot) {
             RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                                          pos_add, S.window, S.kv, i, w.ao));
+                                          pos_add, S.window, S.kv, i, w.ao, frame_ptr));
         } else {
             RT_TRY(launch_qkv_post(ctx, w.qkv, 1, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                                   pos_add, w.q, S.kv, i));
-            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao));
+                                   pos_add, w.q, S.kv, i, frame_ptr));
+            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr));
         }
         ColArgs o;
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
@@ -508,6 +513,8 @@ int rt_model_destroy(rt_model* m) {
     if (m->pad_t) (void)hipFree(m->pad_t);
     if (m->d_frame_srcs) (void)hipFree(m->d_frame_srcs);
     for (auto& e : m->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (m->graph_a) (void)hipGraphExecDestroy(m->graph_a);
+    if (m->graph_b) (void)hipGraphExecDestroy(m->graph_b);
     delete m;
     return RT_OK;
 }
@@ -889,45 +896,43 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     }
     const PackedW& head = PW(m, "talker.codec_head");
 
-    std::vector<int32_t> eos_host((size_t)T_max * B, 0);
-    std::vector<char> done(B, 0);
-    std::vector<int> produced(B, 0);
-    int frames_run = 0;
-    bool cancelled = false;
-    for (int t = 0; t < T_max; ++t) {
-        if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
-        int32_t* codes_t = d_codes + (size_t)t * B * G;
+    int32_t* d_frame = nullptr;
+    uint64_t* d_seed = nullptr;
+    RT_TRY(pool_arr(m, 1, &d_frame));
+    RT_TRY(pool_arr(m, 1, &d_seed));
+    RT_HIP(ctx, hipMemsetAsync(d_frame, 0, 4, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d_seed, &A->seed, 8, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t codes_fs = (int64_t)B * G;
+
+    // ---- frame part A: group 0 from the talker state, then the residual-code predictor.  Every frame-dependent address
+    // is base + *d_frame * stride resolved on the device, so the same launches (or one captured graph) serve every frame.
+    auto enqueue_a = [&]() -> int {
         int ns = 0;
-        // ---- group 0 from the talker state
         if (col) { RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
         else RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
         SampleArgs sa{};
         sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
         sa.do_sample = A->talker.do_sample; sa.temperature = A->talker.temperature; sa.top_k = A->talker.top_k; sa.top_p = A->talker.top_p;
         sa.rep_penalty = A->talker.repetition_penalty; sa.seen = d_seen;
-        sa.suppress_from = c.codebook_size;
-        sa.allow_token = (!A->ignore_eos && t >= A->min_frames) ? c.codec_eos_id : -1;
-        sa.seed = A->seed; sa.item_ids = d_items; sa.frame = t; sa.group = 0;
-        sa.forced = d_forced ? d_forced + ((size_t)t * G + 0) * B : nullptr;
-        sa.out = codes_t; sa.out_stride = G; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos + (size_t)t * B;
-        sa.logits_copy = A->d_trace_talker ? A->d_trace_talker + (size_t)t * B * Vc : nullptr;
+        sa.suppress_from = c.codebook_size; sa.allow_token = -1;
+        sa.seed_ptr = d_seed; sa.item_ids = d_items; sa.frame = 0; sa.group = 0;
+        sa.forced = d_forced; sa.forced_fs = (int64_t)G * B;
+        sa.out = d_codes; sa.out_stride = G; sa.out_fs = codes_fs; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos; sa.eos_fs = B;
+        sa.logits_copy = A->d_trace_talker; sa.copy_fs = (int64_t)B * Vc;
+        sa.frame_ptr = d_frame; sa.eos_live = A->ignore_eos ? 0 : 1; sa.min_frames = A->min_frames;
         RT_TRY(launch_sample(ctx, sa));
-        // ---- predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
+        // predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
             if (col) RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
             else {
                 RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
                 RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
             }
-        }
-        // (index extraction) codes_t has stride G; build a dense index vector with a tiny strided copy
-        RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
-        if (m->has_mtp()) {
-            RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_tmp_idx, B, xp + (size_t)B * Hp, nullptr));
+            RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_codes, B, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
         } else {
             if (col) RT_TRY(launch_add_rmsnorm(ctx, xt, B, H, nullptr, 0, nullptr, nullptr, m->talker.norm, c.talker.rms_eps, nullptr, xp));
             else RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr));
+            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_codes, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
         }
         if (col) {
             RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp));
@@ -948,15 +953,16 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             sp.logits = logits; sp.n_slabs = ns; sp.M = B; sp.V = Vp;
             sp.do_sample = A->predictor.do_sample; sp.temperature = A->predictor.temperature; sp.top_k = A->predictor.top_k;
             sp.top_p = A->predictor.top_p; sp.rep_penalty = 1.0f; sp.seen = nullptr; sp.suppress_from = Vp; sp.allow_token = -1;
-            sp.seed = A->seed; sp.item_ids = d_items; sp.frame = t; sp.group = q + 1;
-            sp.forced = d_forced ? d_forced + ((size_t)t * G + q + 1) * B : nullptr;
-            sp.out = codes_t + q + 1; sp.out_stride = G; sp.eos_token = -1; sp.eos_flag = nullptr;
-            sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + (((size_t)t * (G - 1) + q) * B) * Vp : nullptr;
+            sp.seed_ptr = d_seed; sp.item_ids = d_items; sp.frame = 0; sp.group = q + 1;
+            sp.forced = d_forced ? d_forced + (size_t)(q + 1) * B : nullptr; sp.forced_fs = (int64_t)G * B;
+            sp.out = d_codes + q + 1; sp.out_stride = G; sp.out_fs = codes_fs; sp.eos_token = -1; sp.eos_flag = nullptr; sp.eos_fs = 0;
+            sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + (size_t)q * B * Vp : nullptr;
+            sp.copy_fs = (int64_t)(G - 1) * B * Vp;
+            sp.frame_ptr = d_frame; sp.eos_live = 0; sp.min_frames = 0;
             RT_TRY(launch_sample(ctx, sp));
             if (q < G - 2) {
-                RT_HIP(ctx, hipMemcpy2DAsync(d_tmp_idx, 4, codes_t + q + 1, (size_t)G * 4, 4, B, hipMemcpyDeviceToDevice, ctx->stream));
-                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_tmp_idx, B, xp, nullptr));
-                else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_tmp_idx, B, H, nullptr, nullptr, nullptr, xp, nullptr));
+                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_codes + q + 1, B, xp, nullptr, G, d_frame, codes_fs));
+                else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_codes + q + 1, B, H, nullptr, nullptr, nullptr, xp, nullptr, G, d_frame, codes_fs));
                 if (col) {
                     RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp));
                     RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
@@ -965,6 +971,76 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 }
             }
         }
+        return RT_OK;
+    };
+    // ---- frame part B: next talker input (sum of the frame's G code embeddings + projected tts_pad), talker step, frame += 1
+    auto enqueue_b = [&]() -> int {
+        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_codes, B, H, pad_t, nullptr, nullptr, xt, nullptr, G, d_frame, codes_fs));
+        if (col) {
+            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
+            RT_TRY(stack_decode(m, m->talker, dwt, xt, rowsq_t, B, d_slot_b, d_pos_b, 0, true, d_frame));
+        } else {
+            RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, 0, hn, hn_f32, d_frame));
+        }
+        hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, d_frame);
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    };
+
+    // ---- graphs: capture A and B once per launch signature, replay per frame (1.5-1.8 us per dependent kernel instead of
+    // the ~3 us an eager launch costs on the host: tools/bench_launch.py)
+    bool use_graph = g_use_graph && !m->prof;
+    if (use_graph) {
+        uint64_t sig = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+        for (const void* p : {(const void*)xt, (const void*)xp, (const void*)logits, (const void*)d_codes, (const void*)d_eos, (const void*)d_seen,
+                              (const void*)d_forced, (const void*)A->d_trace_talker, (const void*)A->d_trace_predictor, (const void*)pad_t,
+                              (const void*)d_frame, (const void*)d_seed, (const void*)d_items, (const void*)d_slot_b, (const void*)d_pos_b,
+                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
+                              (const void*)dwp.act, (const void*)wt.slabs, (const void*)wp.slabs, (const void*)hn, (const void*)hn_p,
+                              (const void*)ctx->stream})
+            mix((uint64_t)(uintptr_t)p);
+        mix(B); mix(col); mix(A->ignore_eos); mix(A->min_frames);
+        for (const rt_sampling* sp : {&A->talker, &A->predictor}) {
+            mix(sp->do_sample); mix(sp->top_k);
+            uint32_t f;
+            memcpy(&f, &sp->temperature, 4); mix(f);
+            memcpy(&f, &sp->top_p, 4); mix(f);
+            memcpy(&f, &sp->repetition_penalty, 4); mix(f);
+        }
+        if (sig != m->graph_sig || !m->graph_a || !m->graph_b) {
+            if (m->graph_a) { (void)hipGraphExecDestroy(m->graph_a); m->graph_a = nullptr; }
+            if (m->graph_b) { (void)hipGraphExecDestroy(m->graph_b); m->graph_b = nullptr; }
+            m->graph_sig = 0;
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int which = 0; which < 2; ++which) {
+                hipGraph_t gr = nullptr;
+                RT_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = which == 0 ? enqueue_a() : enqueue_b();
+                const hipError_t ce = hipStreamEndCapture(ctx->stream, &gr);
+                if (rc || ce != hipSuccess) {
+                    if (gr) (void)hipGraphDestroy(gr);
+                    return rc ? rc : rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph capture failed: %s", hipGetErrorString(ce));
+                }
+                hipGraphExec_t ex = nullptr;
+                const hipError_t ie = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(gr);
+                if (ie != hipSuccess) return rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph instantiate failed: %s", hipGetErrorString(ie));
+                (which == 0 ? m->graph_a : m->graph_b) = ex;
+            }
+            m->graph_sig = sig;
+        }
+    }
+
+    std::vector<int32_t> eos_host((size_t)T_max * B, 0);
+    std::vector<char> done(B, 0);
+    std::vector<int> produced(B, 0);
+    int frames_run = 0;
+    bool cancelled = false;
+    for (int t = 0; t < T_max; ++t) {
+        if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
+        if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graph_a, ctx->stream));
+        else RT_TRY(enqueue_a());
         frames_run = t + 1;
         // ---- stop bookkeeping (needs the eos flags on the host only when eos is live)
         bool all_done = true;
@@ -980,14 +1056,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             all_done = all_done && done[b];
         }
         if (all_done) break;
-        // ---- next talker input: sum of the frame's G code embeddings + projected tts_pad
-        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes_t, B, H, pad_t, nullptr, nullptr, xt, nullptr));
-        if (col) {
-            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
-            RT_TRY(stack_decode(m, m->talker, dwt, xt, rowsq_t, B, d_slot_b, d_pos_b, t));
-        } else {
-            RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, t, hn, hn_f32));
-        }
+        if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graph_b, ctx->stream));
+        else RT_TRY(enqueue_b());
     }
     // ---- results
     std::vector<int32_t> codes_host((size_t)std::max(frames_run, 1) * B * G);

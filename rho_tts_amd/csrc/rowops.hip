@@ -123,11 +123,11 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
                                                  float eps, const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                  const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
                                                  int pos_add, float* __restrict__ q_out, bf16_t* __restrict__ kc,
-                                                 bf16_t* __restrict__ vc, int max_pos) {
+                                                 bf16_t* __restrict__ vc, int max_pos, const int32_t* __restrict__ frame_ptr) {
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int width = (heads + 2 * kv_heads) * d;
     const int half = d >> 1;
-    const int pos = row_pos[row] + pos_add, slot = row_slot[row];
+    const int pos = row_pos[row] + pos_add + (frame_ptr ? *frame_ptr : 0), slot = row_slot[row];
     // lane handles element pairs (i, i + half) for i = lane, lane+64, ...  (half <= 64 for d <= 128)
     float a = 0.f, b = 0.f;
     const bool act = lane < half;
@@ -168,8 +168,10 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
 __global__ __launch_bounds__(256) void k_gather_sum(const GatherSrc* __restrict__ srcs, int n_src, const int32_t* __restrict__ idx,
                                                     int H, const float* __restrict__ add_vec, const float* __restrict__ add_rows,
                                                     const int32_t* __restrict__ add_row_idx, float* __restrict__ out_f32,
-                                                    bf16_t* __restrict__ out_bf16) {
+                                                    bf16_t* __restrict__ out_bf16, int idx_stride,
+                                                    const int32_t* __restrict__ frame_ptr, int64_t idx_frame_stride) {
     const int64_t row = blockIdx.x;
+    if (frame_ptr) idx += (int64_t)(*frame_ptr) * idx_frame_stride;
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = add_vec ? add_vec[i] : 0.f;
         if (add_rows) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void k_gather_sum(const GatherSrc* __restrict_
             if (ar >= 0) v += add_rows[(int64_t)ar * H + i];
         }
         for (int j = 0; j < n_src; ++j) {
-            const int id = idx[row * n_src + j];
+            const int id = idx[row * idx_stride + j];
             if (id >= 0) v += bf16_to_f32(srcs[j].table[(int64_t)id * srcs[j].row_stride + i]);
         }
         if (out_f32) out_f32[row * H + i] = v;
@@ -186,9 +188,11 @@ __global__ __launch_bounds__(256) void k_gather_sum(const GatherSrc* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_gather_f32(const float* __restrict__ table, int H, const int32_t* __restrict__ idx,
-                                                    float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16) {
+                                                    float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16, int idx_stride,
+                                                    const int32_t* __restrict__ frame_ptr, int64_t idx_frame_stride) {
     const int64_t row = blockIdx.x;
-    const int id = idx[row];
+    if (frame_ptr) idx += (int64_t)(*frame_ptr) * idx_frame_stride;
+    const int id = idx[row * idx_stride];
     for (int i = threadIdx.x; i < H; i += 256) {
         const float v = id >= 0 ? table[(int64_t)id * H + i] : 0.f;
         if (out_f32) out_f32[row * H + i] = v;
@@ -323,29 +327,32 @@ int launch_reduce_slabs(rt_ctx* ctx, const float* slabs, int n_slabs, int64_t M,
 
 int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                     const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
-                    const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer) {
+                    const int32_t* row_pos, int pos_add, float* q_out, const KvCache& kv, int layer, const int32_t* frame_ptr) {
     if (M <= 0) return RT_OK;
     if (head_dim > 128 || (head_dim & 1)) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "head_dim %d unsupported (even, <= 128)", head_dim);
     const int width = (heads + 2 * kv_heads) * head_dim;
     hipLaunchKernelGGL(k_qkv_post, dim3(M, heads + 2 * kv_heads), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * width, heads,
                        kv_heads, head_dim, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, q_out,
-                       kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(), kv.max_pos);
+                       kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(), kv.max_pos, frame_ptr);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 
 int launch_gather_sum(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const int32_t* d_idx, int M, int H, const float* add_vec,
-                      const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16) {
+                      const float* add_rows, const int32_t* add_row_idx, float* out_f32, bf16_t* out_bf16, int idx_stride,
+                      const int32_t* frame_ptr, int64_t idx_frame_stride) {
     if (M <= 0) return RT_OK;
     hipLaunchKernelGGL(k_gather_sum, dim3(M), dim3(256), 0, ctx->stream, d_srcs, n_src, d_idx, H, add_vec, add_rows, add_row_idx, out_f32,
-                       out_bf16);
+                       out_bf16, idx_stride > 0 ? idx_stride : n_src, frame_ptr, idx_frame_stride);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 
-int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16) {
+int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_idx, int M, float* out_f32, bf16_t* out_bf16,
+                      int idx_stride, const int32_t* frame_ptr, int64_t idx_frame_stride) {
     if (M <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_gather_f32, dim3(M), dim3(256), 0, ctx->stream, table, H, d_idx, out_f32, out_bf16);
+    hipLaunchKernelGGL(k_gather_f32, dim3(M), dim3(256), 0, ctx->stream, table, H, d_idx, out_f32, out_bf16, idx_stride, frame_ptr,
+                       idx_frame_stride);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
