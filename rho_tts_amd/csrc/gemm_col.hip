@@ -28,14 +28,18 @@ __device__ __forceinline__ f16_t mfma32(s8_t a, s8_t b, f16_t c) {
 }
 __device__ __forceinline__ unsigned pk2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
 
-constexpr int WAVES = 16;   // 1024 threads: 4 waves per SIMD, every one with its own weight run in flight
+constexpr int WAVES = 8;    // 512 threads, 2 waves per SIMD: 256 VGPRs per wave for deep load queues
 
+// One memory round trip per K super-chunk: the weight tiles, the raw activation fragments, the RMSNorm partials and the
+// residual values the epilogue will update are ALL requested before anything is waited for; super-chunk s+1 is in flight
+// while s is converted and multiplied.
 template <int MT, bool NORM, int EPI>
-__global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
-    __shared__ float red[8][16][64];       // 32 KiB: accumulator tiles of 8 waves at a time
-    __shared__ float sh_inv[64];           // RMSNorm row scales
+__global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
+    __shared__ float red[WAVES][16][64];   // 32 KiB: one accumulator tile per wave
+    __shared__ float sh_inv[32];           // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int U = NORM ? (NB == 1 ? 4 : 2) : (NB == 1 ? 8 : 4);   // k-tiles in flight per wave (128-VGPR budget, no spills)
+    constexpr int C = (NB == 2) ? 4 : 8;   // k-tiles per super-chunk
+    static_assert(MT == 1, "row blocks of 32");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nt = blockIdx.x;
@@ -44,24 +48,54 @@ __global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
     int kt_hi = kt_lo + kchunk;
     if (kt_hi > g.KT) kt_hi = g.KT;
     const int n_k = kt_hi > kt_lo ? kt_hi - kt_lo : 0;
+    const int n_sc = (n_k + C - 1) / C;
 
     const s8_t* wp[NB];
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
+    const int arow = r < g.M ? r : g.M - 1;          // clamp: computed on valid memory, never stored
+    const char* abase = reinterpret_cast<const char*>(g.A) + ((int64_t)arow * g.K + (int64_t)kt_lo * 16 + h * 8) * (NORM ? 4 : 2);
 
-    // first weight loads go out before anything else: they are the long pole
-    s8_t bw[NB][U];
+    struct Chunk {
+        s8_t b[NB][C];
+        f4_t a32[NORM ? C : 1][2];
+        s8_t a16[NORM ? 1 : C];
+    };
+    auto issue = [&](int sc, Chunk& ck) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+        for (int u = 0; u < C; ++u) {
+            int k = sc * C + u;
+            if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = u < n_k ? u : (n_k > 0 ? n_k - 1 : 0);
-            if (n_k > 0) bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
+            for (int b = 0; b < NB; ++b) ck.b[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
+            if (NORM) {
+                const f4_t* xp = reinterpret_cast<const f4_t*>(abase + (int64_t)k * 64);
+                ck.a32[NORM ? u : 0][0] = xp[0];
+                ck.a32[NORM ? u : 0][1] = xp[1];
+            } else {
+                ck.a16[NORM ? 0 : u] = *reinterpret_cast<const s8_t*>(abase + (int64_t)k * 32);
+            }
         }
+    };
 
-    if (NORM) {   // row scales once per workgroup: half-wave (w, h) owns row 2w + h, its 32 lanes split the partials
-        const int row_i = 2 * w + h;
-        if (row_i < MT * 32) {
+    Chunk c0, c1;
+    if (n_sc > 0) issue(0, c0);
+    // residual values this thread will update in the epilogue (elements tid and tid + 512 of the 32x32 tile)
+    const int n = nt * 32 + (tid & 31);
+    const int e_h = (tid >> 5) & 1;
+    float xres[2] = {0.f, 0.f};
+    if (EPI == COL_RESID) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = (tid + q * 512) >> 6;
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
+            if (row < g.M && n < g.N) xres[q] = g.out[(int64_t)row * g.ldc + n];
+        }
+    }
+    if (NORM) {   // row scales: half-wave (w, h) owns rows 2w + h and 2w + h + 16, its 32 lanes split the partials
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row_i = 2 * w + h + 16 * rr;
             const int row = row_i < g.M ? row_i : g.M - 1;
             const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
             float s = 0.f;
@@ -70,130 +104,95 @@ __global__ __launch_bounds__(1024) void k_gemm_col(ColArgs g) {
             for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
         }
-        __syncthreads();
     }
-    int arow[MT];
-    float inv[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int row = mt * 32 + r;
-        if (row >= g.M) row = g.M - 1;   // clamp: computed on valid memory, never stored
-        arow[mt] = row;
-        inv[mt] = NORM ? sh_inv[mt * 32 + r] : 1.f;
-    }
+    if (n_sc > 1) issue(1, c1);
+    __syncthreads();
+    const float inv = NORM ? sh_inv[r] : 1.f;
 
-    f16_t acc[NB][MT];
+    f16_t acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[b][mt][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
 
-    for (int kt = 0; kt < n_k; kt += U) {
-        if (kt > 0) {
+    auto consume = [&](int sc, Chunk& ck) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+        for (int u = 0; u < C; ++u) {
+            const int k = sc * C + u;
+            s8_t af;
+            if (NORM) {
+                const float* wn = g.norm_w + (kt_lo + (k < n_k ? k : n_k - 1)) * 16 + h * 8;
+                const f4_t w0 = *reinterpret_cast<const f4_t*>(wn), w1 = *reinterpret_cast<const f4_t*>(wn + 4);
+                const f4_t x0 = ck.a32[NORM ? u : 0][0], x1 = ck.a32[NORM ? u : 0][1];
+                i4_t pk;
+                pk[0] = (int)pk2(w0[0] * (x0[0] * inv), w0[1] * (x0[1] * inv));
+                pk[1] = (int)pk2(w0[2] * (x0[2] * inv), w0[3] * (x0[3] * inv));
+                pk[2] = (int)pk2(w1[0] * (x1[0] * inv), w1[1] * (x1[1] * inv));
+                pk[3] = (int)pk2(w1[2] * (x1[2] * inv), w1[3] * (x1[3] * inv));
+                af = __builtin_bit_cast(s8_t, pk);
+            } else {
+                af = ck.a16[NORM ? 0 : u];
+            }
+            if (k < n_k) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int k = kt + u < n_k ? kt + u : n_k - 1;      // tail: re-load the last tile, result discarded
-                    bw[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
-                }
+                for (int b = 0; b < NB; ++b) acc[b] = mfma32(af, ck.b[b][u], acc[b]);
+            }
         }
-        s8_t af[MT][U];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = kt + u < n_k ? kt + u : n_k - 1;
-                const int64_t off = (int64_t)arow[mt] * g.K + (int64_t)(kt_lo + k) * 16 + h * 8;
-                if (NORM) {
-                    const float* xp = reinterpret_cast<const float*>(g.A) + off;
-                    const f4_t x0 = *reinterpret_cast<const f4_t*>(xp), x1 = *reinterpret_cast<const f4_t*>(xp + 4);
-                    const float* wn = g.norm_w + (kt_lo + k) * 16 + h * 8;
-                    const f4_t w0 = *reinterpret_cast<const f4_t*>(wn), w1 = *reinterpret_cast<const f4_t*>(wn + 4);
-                    i4_t pk;
-                    pk[0] = (int)pk2(w0[0] * (x0[0] * inv[mt]), w0[1] * (x0[1] * inv[mt]));
-                    pk[1] = (int)pk2(w0[2] * (x0[2] * inv[mt]), w0[3] * (x0[3] * inv[mt]));
-                    pk[2] = (int)pk2(w1[0] * (x1[0] * inv[mt]), w1[1] * (x1[1] * inv[mt]));
-                    pk[3] = (int)pk2(w1[2] * (x1[2] * inv[mt]), w1[3] * (x1[3] * inv[mt]));
-                    af[mt][u] = __builtin_bit_cast(s8_t, pk);
-                } else {
-                    af[mt][u] = *reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.A) + off);
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (kt + u < n_k) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[b][mt] = mfma32(af[mt][u], bw[b][u], acc[b][mt]);
-            }
+    };
+    for (int sc = 0; sc < n_sc; sc += 2) {
+        consume(sc, c0);
+        if (sc + 2 < n_sc) issue(sc + 2, c0);
+        if (sc + 1 < n_sc) {
+            consume(sc + 1, c1);
+            if (sc + 3 < n_sc) issue(sc + 3, c1);
         }
     }
 
-    // ---- combine the 16 K-partials through LDS in a fixed order (waves 8-15 fold into 0-7, then 8 -> 1) and run the
-    // fused epilogue, one accumulator tile at a time
-    const int n = nt * 32 + (tid & 31);          // column of this thread in the reduce phase
-    const int e_h = (tid >> 5) & 1;              // which half-wave -> +4 rows
+    // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue
+    float val[NB][2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        float val[NB];
+    for (int b = 0; b < NB; ++b) {
+        if (b > 0) __syncthreads();
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            __syncthreads();
-            if (w >= 8) {
+        for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[b][i];
+        __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 16; ++i) red[w - 8][i][lane] = acc[b][mt][i];
-            }
-            __syncthreads();
-            if (w < 8) {
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * 512;
+            const int i = e >> 6, l = e & 63;
+            float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[b][mt][i] += red[w][i][lane];
-            }
-            __syncthreads();
-            if (w < 8) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[b][mt][i];
-            }
-            __syncthreads();
-            {
-                const int i = tid >> 6, l = tid & 63;     // 1024 threads = 16 x 64 elements of the 32x32 tile
-                float s = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) s += red[ww][i][l];
-                val[b] = s;
-            }
+            for (int ww = 0; ww < WAVES; ++ww) s += red[ww][i][l];
+            val[b][q] = s;
         }
-        {
-            const int i = tid >> 6;
-            const int row = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * e_h;
-            const bool ok = row < g.M && n < g.N;
-            float v = val[0];
-            if (EPI == COL_STORE) {
-                if (ok) {
-                    if (g.bias) v += g.bias[n];
-                    g.out[(int64_t)row * g.ldc + n] = v;
-                }
-            } else if (EPI == COL_RESID) {
-                float xn = 0.f;
-                if (ok) {
-                    if (g.bias) v += g.bias[n];
-                    if (g.scale) v *= g.scale[n];
-                    float* xp = g.out + (int64_t)row * g.ldc + n;
-                    xn = *xp + v;
-                    *xp = xn;
-                }
-                float sq = xn * xn;                   // half-wave = one row's 32 columns
+    }
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-                if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)row * g.rowsq_out_n + nt] = sq;
-            } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
-                if (ok) {
-                    const float u = val[NB - 1];
-                    g.out_bf16[(int64_t)row * g.ldc + n] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
-                }
+    for (int q = 0; q < 2; ++q) {
+        const int i = (tid + q * 512) >> 6;
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
+        const bool ok = row < g.M && n < g.N;
+        float v = val[0][q];
+        if (EPI == COL_STORE) {
+            if (ok) {
+                if (g.bias) v += g.bias[n];
+                g.out[(int64_t)row * g.ldc + n] = v;
+            }
+        } else if (EPI == COL_RESID) {
+            float xn = 0.f;
+            if (ok) {
+                if (g.bias) v += g.bias[n];
+                if (g.scale) v *= g.scale[n];
+                xn = xres[q] + v;
+                g.out[(int64_t)row * g.ldc + n] = xn;
+            }
+            float sq = xn * xn;                   // half-wave = one row's 32 columns
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)row * g.rowsq_out_n + nt] = sq;
+        } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
+            if (ok) {
+                const float u = val[NB - 1][q];
+                g.out_bf16[(int64_t)row * g.ldc + n] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
             }
         }
     }
@@ -203,18 +202,18 @@ template <int MT, bool NORM>
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     if (!e0 && !e1) {   // plain launches are what a stream capture records
         switch (g.epi) {
-            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(1024), 0, ctx->stream, g); break;
-            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(1024), 0, ctx->stream, g); break;
-            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(1024), 0, ctx->stream, g); break;
+            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(512), 0, ctx->stream, g); break;
+            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(512), 0, ctx->stream, g); break;
+            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(512), 0, ctx->stream, g); break;
             default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
         }
         RT_HIP(ctx, hipGetLastError());
         return RT_OK;
     }
     switch (g.epi) {
-        case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(1024), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+        case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
         default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
