@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
                                                    int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                    int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
-                                                   const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr) {
+                                                   const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
@@ -163,19 +163,21 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
             lt += sh[ww][r][sb][1] * c;
             at += sh[ww][r][sb][2 + j] * c;
         }
-        out[((int64_t)row * heads + kh * REP + r) * D + sb * 8 + j] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
+        const int kcol = (kh * REP + r) * D + sb * 8 + j;
+        const int64_t oo = out_tiled ? tile_off(row, kcol, (heads * D) >> 4) : (int64_t)row * heads * D + kcol;
+        out[oo] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
     }
 }
 
-struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; };
+struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; };
 
 template <int D, bool FUSED>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -202,16 +204,17 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
 }  // namespace
 
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
-                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr) {
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled) {
     FusedArgs f{};
     f.frame_ptr = frame_ptr;
+    f.out_tiled = out_tiled;
     return attention_any<false>(ctx, q, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }
 
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr) {
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr};
+                           const int32_t* frame_ptr, int out_tiled) {
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

@@ -73,6 +73,14 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
+// Fragment-tiled activation layout shared by the decode kernels: a [rows][K] matrix is stored as
+// [row block of 32][k tile of 16][lane = (k half << 5) | row][8 elements], i.e. exactly the A-operand order of
+// v_mfma_f32_32x32x16_bf16, so a wave fetches an operand tile with ONE fully coalesced load instead of 32 row-strided
+// pieces.  KT = K / 16.
+__host__ __device__ __forceinline__ int64_t tile_off(int m, int k, int KT) {
+    return ((((int64_t)(m >> 5) * KT + (k >> 4)) * 64 + ((((k >> 3) & 1) << 5) | (m & 31))) << 3) + (k & 7);
+}
+
 // bf16 <-> f32 (round-to-nearest-even, NaN preserved by the hardware cast on gfx950)
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }

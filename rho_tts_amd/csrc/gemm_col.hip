@@ -53,8 +53,9 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     const s8_t* wp[NB];
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
-    const int arow = r < g.M ? r : g.M - 1;          // clamp: computed on valid memory, never stored
-    const char* abase = reinterpret_cast<const char*>(g.A) + ((int64_t)arow * g.K + (int64_t)kt_lo * 16 + h * 8) * (NORM ? 4 : 2);
+    const int arow = g.row_off + (r < g.M ? r : g.M - 1);          // clamp: computed on valid memory, never stored
+    // fragment-tiled A: this lane's 8 elements of k-tile kt sit at tile_off(arow, 16 kt + 8 h); consecutive lanes are contiguous
+    const char* abase = reinterpret_cast<const char*>(g.A) + tile_off(arow, kt_lo * 16 + h * 8, g.KT) * (NORM ? 4 : 2);
 
     struct Chunk {
         s8_t b[NB][C];
@@ -69,11 +70,11 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) ck.b[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
             if (NORM) {
-                const f4_t* xp = reinterpret_cast<const f4_t*>(abase + (int64_t)k * 64);
+                const f4_t* xp = reinterpret_cast<const f4_t*>(abase + (int64_t)k * 2048);
                 ck.a32[NORM ? u : 0][0] = xp[0];
                 ck.a32[NORM ? u : 0][1] = xp[1];
             } else {
-                ck.a16[NORM ? 0 : u] = *reinterpret_cast<const s8_t*>(abase + (int64_t)k * 32);
+                ck.a16[NORM ? 0 : u] = *reinterpret_cast<const s8_t*>(abase + (int64_t)k * 1024);
             }
         }
     };
@@ -89,14 +90,14 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         for (int q = 0; q < 2; ++q) {
             const int i = (tid + q * 512) >> 6;
             const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
-            if (row < g.M && n < g.N) xres[q] = g.out[(int64_t)row * g.ldc + n];
+            if (row < g.M && n < g.N) xres[q] = g.out[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))];
         }
     }
     if (NORM) {   // row scales: half-wave (w, h) owns rows 2w + h and 2w + h + 16, its 32 lanes split the partials
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row_i = 2 * w + h + 16 * rr;
-            const int row = row_i < g.M ? row_i : g.M - 1;
+            const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
             const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
             float s = 0.f;
             for (int j = r; j < g.rowsq_n; j += 32) s += p[j];
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         if (EPI == COL_STORE) {
             if (ok) {
                 if (g.bias) v += g.bias[n];
-                g.out[(int64_t)row * g.ldc + n] = v;
+                g.out[(int64_t)(g.row_off + row) * g.ldc + n] = v;      // STORE outputs (qkv, logits, mtp rows) stay row-major
             }
         } else if (EPI == COL_RESID) {
             float xn = 0.f;
@@ -183,16 +184,16 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
                 if (g.bias) v += g.bias[n];
                 if (g.scale) v *= g.scale[n];
                 xn = xres[q] + v;
-                g.out[(int64_t)row * g.ldc + n] = xn;
+                g.out[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))] = xn;
             }
             float sq = xn * xn;                   // half-wave = one row's 32 columns
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)row * g.rowsq_out_n + nt] = sq;
+            if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)(g.row_off + row) * g.rowsq_out_n + nt] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
                 const float u = val[NB - 1][q];
-                g.out_bf16[(int64_t)row * g.ldc + n] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
+                g.out_bf16[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
             }
         }
     }

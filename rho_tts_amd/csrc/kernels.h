@@ -68,7 +68,9 @@ extern int g_skinny_waves_per_cu;
 // Column-owner decode GEMM (gemm_col.hip): whole-K per workgroup, fused RMSNorm prologue and residual / SwiGLU epilogues.
 enum { COL_STORE = 0, COL_RESID = 1, COL_SILU = 2 };
 struct ColArgs {
-    const void* A = nullptr;        // bf16 [M][K], or the f32 residual stream [M][K] when a_norm
+    // All activations of the column path are fragment-tiled (common.h tile_off); STORE outputs stay row-major.
+    int row_off = 0;                // first row (in the tiled A / x / act buffers) of this 32-row block
+    const void* A = nullptr;        // tiled bf16 [rows][K], or the tiled f32 residual stream when a_norm
     int a_norm = 0;                 // 1: A is f32; apply rsqrt(sum(rowsq)/K + eps) * norm_w while loading
     const float* rowsq = nullptr;   // [M][rowsq_n] partial sums of squares of A's rows
     int rowsq_n = 0;
@@ -89,7 +91,7 @@ struct ColArgs {
 };
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)
-int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n);
+int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr);
 
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
@@ -117,7 +119,7 @@ int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int hea
 // o[M][heads*d] (bf16) = softmax(q k^T / sqrt(d)) v over cache rows [max(0,pos-window+1), pos] of the row's slot
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
                      const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                     const int32_t* frame_ptr = nullptr);
+                     const int32_t* frame_ptr = nullptr, int out_tiled = 0);
 
 // Every launch that depends on the frame index takes `frame_ptr` (device int, nullptr = 0): positions are
 // row_pos + pos_add + *frame_ptr, so one captured hipGraph serves every frame of the decode loop.
@@ -125,7 +127,7 @@ int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr = nullptr);
+                           const int32_t* frame_ptr = nullptr, int out_tiled = 0);
 
 // ------------------------------------------------------------------------------ embedding kernels
 // out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.

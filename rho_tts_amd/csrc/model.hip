@@ -363,12 +363,15 @@ struct DecWs {
     bf16_t* ao = nullptr;   // [M][q_dim]
     bf16_t* act = nullptr;  // [M][inter]
     float* q = nullptr;     // [M][q_dim] (only for passes with several rows per slot)
+    float* xT = nullptr;    // fragment-tiled residual stream [ceil(M/32)*32][H]
 };
 int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
+    const size_t Mp = (size_t)(M + 31) / 32 * 32;     // tiled buffers hold whole 32-row blocks
+    RT_TRY(pool_arr(m, Mp * d.hidden, &w->xT));
     RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
     RT_TRY(pool_arr(m, (size_t)M * (d.heads + 2 * d.kv_heads) * d.head_dim, &w->qkv));
-    RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->ao));
-    RT_TRY(pool_arr(m, (size_t)M * d.inter, &w->act));
+    RT_TRY(pool_arr(m, Mp * d.heads * d.head_dim, &w->ao));
+    RT_TRY(pool_arr(m, Mp * d.inter, &w->act));
     return RT_OK;
 }
 // Row blocks of 32: a 64-row pass (the predictor's first, 2 rows per sequence) streams the weights twice.
@@ -376,12 +379,7 @@ int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W) {
     for (int r0 = 0; r0 < a0.M; r0 += 32) {
         ColArgs a = a0;
         a.M = std::min(32, a0.M - r0);
-        const size_t a_el = a0.a_norm ? 4 : 2;
-        a.A = (const char*)a0.A + (size_t)r0 * a0.K * a_el;
-        if (a0.rowsq) a.rowsq = a0.rowsq + (size_t)r0 * a0.rowsq_n;
-        if (a0.out) a.out = a0.out + (size_t)r0 * a0.ldc;
-        if (a0.out_bf16) a.out_bf16 = a0.out_bf16 + (size_t)r0 * a0.ldc;
-        if (a0.rowsq_out) a.rowsq_out = a0.rowsq_out + (size_t)r0 * a0.rowsq_out_n;
+        a.row_off = a0.row_off + r0;
         hipEvent_t e0, e1;
         prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
         RT_TRY(launch_gemm_col(m->ctx, a, W, e0, e1));
@@ -403,11 +401,11 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         RT_TRY(col_gemm(m, a, L.wqkv));
         if (one_row_per_slot) {
             RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                                          pos_add, S.window, S.kv, i, w.ao, frame_ptr));
+                                          pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1));
         } else {
             RT_TRY(launch_qkv_post(ctx, w.qkv, 1, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
                                    pos_add, w.q, S.kv, i, frame_ptr));
-            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr));
+            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1));
         }
         ColArgs o;
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
@@ -425,11 +423,12 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
     return RT_OK;
 }
 // out[M][N] = rmsnorm(x) W^T (+ bias): LM heads and the mtp projection, final norm applied in the GEMM prologue
-int col_head(rt_model* m, const float* x, const float* rowsq, int rowsq_n, int M, int K, const float* norm_w, float eps, const PackedW& W,
-             const float* bias, float* out) {
+// x is the fragment-tiled residual stream; rows [row_off, row_off + M) are read, out rows 0.. are written row-major
+int col_head(rt_model* m, const float* xT, const float* rowsq, int rowsq_n, int row_off, int M, int K, const float* norm_w, float eps,
+             const PackedW& W, const float* bias, float* out) {
     ColArgs a;
-    a.A = x; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.norm_w = norm_w; a.M = M; a.K = K;
-    a.epi = COL_STORE; a.out = out; a.ldc = W.N; a.bias = bias;
+    a.A = xT; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.norm_w = norm_w; a.M = M; a.K = K; a.row_off = row_off;
+    a.epi = COL_STORE; a.out = out - (size_t)row_off * W.N; a.ldc = W.N; a.bias = bias;
     return col_gemm(m, a, W);
 }
 
@@ -875,7 +874,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_HIP(ctx, hipMemcpyAsync(d_forced, forced_host.data(), forced_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     // decode state.  Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
-    const bool col = g_decode_col && B2 <= 64;
+    const bool col = g_decode_col && B2 <= 64 && m->has_mtp();   // (equal-width predictor: the legacy path materialises the past hidden)
     const int NTt = H / 32, NTp = Hp / 32;
     float *rowsq_t = nullptr, *rowsq_p = nullptr, *x_all = x;
     DecWs dwt, dwp;
@@ -887,7 +886,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(alloc_dec_ws(m, c.predictor, B2, &dwp));
         // xt <- residual-stream rows (before the final norm) of each item's last prompt position
         RT_TRY(launch_gather_f32(ctx, x_all, H, d_last, B, xt, nullptr));
-        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
+        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT));
     } else {
         // hn <- final-norm rows of each item's last prompt position
         RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
@@ -908,7 +907,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // is base + *d_frame * stride resolved on the device, so the same launches (or one captured graph) serve every frame.
     auto enqueue_a = [&]() -> int {
         int ns = 0;
-        if (col) { RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
+        if (col) { RT_TRY(col_head(m, dwt.xT, rowsq_t, NTt, 0, B, H, m->talker.norm, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
         else RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
         SampleArgs sa{};
         sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
@@ -923,27 +922,26 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(launch_sample(ctx, sa));
         // predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
-            if (col) RT_TRY(col_head(m, xt, rowsq_t, NTt, B, H, m->talker.norm, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
+            if (col) RT_TRY(col_head(m, dwt.xT, rowsq_t, NTt, 0, B, H, m->talker.norm, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
             else {
                 RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
                 RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
             }
             RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_codes, B, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
         } else {
-            if (col) RT_TRY(launch_add_rmsnorm(ctx, xt, B, H, nullptr, 0, nullptr, nullptr, m->talker.norm, c.talker.rms_eps, nullptr, xp));
-            else RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
             RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_codes, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
         }
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp));
-            RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B2, d_slot_b, d_pos_p2, 0, false));
+            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp, dwp.xT));
+            RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B2, d_slot_b, d_pos_p2, 0, false));
         } else {
             RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
         }
         for (int q = 0; q < G - 1; ++q) {
             const size_t roff = (q == 0) ? (size_t)B : 0;      // the first head reads the rows of position 1
             if (col) {
-                RT_TRY(col_head(m, xp + roff * Hp, rowsq_p + roff * NTp, NTp, B, Hp, m->pred.norm, c.predictor.rms_eps,
+                RT_TRY(col_head(m, dwp.xT, rowsq_p, NTp, (int)roff, B, Hp, m->pred.norm, c.predictor.rms_eps,
                                 PW(m, "pred.head" + std::to_string(q)), nullptr, logits));
                 ns = 1;
             } else {
@@ -964,8 +962,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_codes + q + 1, B, xp, nullptr, G, d_frame, codes_fs));
                 else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_codes + q + 1, B, H, nullptr, nullptr, nullptr, xp, nullptr, G, d_frame, codes_fs));
                 if (col) {
-                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp));
-                    RT_TRY(stack_decode(m, m->pred, dwp, xp, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
+                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp, dwp.xT));
+                    RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
                 } else {
                     RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
                 }
@@ -977,8 +975,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     auto enqueue_b = [&]() -> int {
         RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_codes, B, H, pad_t, nullptr, nullptr, xt, nullptr, G, d_frame, codes_fs));
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt));
-            RT_TRY(stack_decode(m, m->talker, dwt, xt, rowsq_t, B, d_slot_b, d_pos_b, 0, true, d_frame));
+            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT));
+            RT_TRY(stack_decode(m, m->talker, dwt, dwt.xT, rowsq_t, B, d_slot_b, d_pos_b, 0, true, d_frame));
         } else {
             RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, 0, hn, hn_f32, d_frame));
         }
@@ -996,7 +994,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         for (const void* p : {(const void*)xt, (const void*)xp, (const void*)logits, (const void*)d_codes, (const void*)d_eos, (const void*)d_seen,
                               (const void*)d_forced, (const void*)A->d_trace_talker, (const void*)A->d_trace_predictor, (const void*)pad_t,
                               (const void*)d_frame, (const void*)d_seed, (const void*)d_items, (const void*)d_slot_b, (const void*)d_pos_b,
-                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
+                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.xT, (const void*)dwp.xT, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
                               (const void*)dwp.act, (const void*)wt.slabs, (const void*)wp.slabs, (const void*)hn, (const void*)hn_p,
                               (const void*)ctx->stream})
             mix((uint64_t)(uintptr_t)p);
