@@ -84,9 +84,14 @@ __host__ __device__ __forceinline__ int64_t tile_off(int m, int k, int KT) {
 // bf16 <-> f32 (round-to-nearest-even, NaN preserved by the hardware cast on gfx950)
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even by the hardware converter (v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN) - the integer
+// emulation costs ~10 VALU instructions per element, which showed up as microseconds in the conversion-heavy kernels
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 rt_bf2_t;
+__device__ __forceinline__ unsigned f32x2_to_bf16x2(float lo, float hi) {
+    const rt_bf2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
 }

@@ -24,7 +24,7 @@ __device__ __forceinline__ f16_t mfma32(s8_t a, s8_t b, f16_t c) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    return f32x2_to_bf16x2(lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------ pack

@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(4))) int i4_t;
 __device__ __forceinline__ f16_t mfma32(s8_t a, s8_t b, f16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ unsigned pk2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+__device__ __forceinline__ unsigned pk2(float lo, float hi) { return f32x2_to_bf16x2(lo, hi); }
 
 constexpr int WAVES = 8;    // 512 threads, 2 waves per SIMD: 256 VGPRs per wave for deep load queues
 
