@@ -3,8 +3,8 @@
 // non-temporal 1-KiB loads (each weight byte is read exactly once, by exactly one wave), partial accumulators are
 // combined through LDS in a fixed order (deterministic, no float atomics, no partial slabs in HBM), and because a
 // workgroup sees complete dot products the layer's elementwise work is fused into the GEMM:
-//   prologue  NORM  : A is the f32 residual stream; RMSNorm (row scale from the producer's sum-of-squares partials,
-//                     times the norm weight) is applied while the fragment is loaded, then rounded to bf16
+//   RMSNorm         : the operand is bf16(w .* x) written by the producer; the row scale 1/rms comes from the producer's
+//                     sum-of-squares partials and is applied to the accumulator (y = inv_row * ((w .* x) W^T))
 //   epilogue  STORE : out = acc (+ bias)
 //             RESID : x += scale * acc (residual stream updated in place) and per-(row, tile) sums of squares of the
 //                     NEW x are emitted for the next GEMM's NORM prologue
@@ -30,16 +30,16 @@ __device__ __forceinline__ unsigned pk2(float lo, float hi) { return f32x2_to_bf
 
 constexpr int WAVES = 8;    // 512 threads, 2 waves per SIMD: 256 VGPRs per wave for deep load queues
 
-// One memory round trip per K super-chunk: the weight tiles, the raw activation fragments, the RMSNorm partials and the
-// residual values the epilogue will update are ALL requested before anything is waited for; super-chunk s+1 is in flight
-// while s is converted and multiplied.
-template <int MT, bool NORM, int EPI>
+// RMSNorm without touching the operand twice: y = rmsnorm(x) W^T = inv_row * ((w .* x) W^T).  The producer of x (the
+// RESID epilogue, or k_rowsq for the first GEMM of a stack) already stored bf16(w_next .* x) in fragment-tiled order, so
+// every GEMM reads a plain bf16 operand with one coalesced load per tile, and the row scale inv_row - from the
+// producer's per-tile sums of squares - is applied to the accumulator in the epilogue (post_scale).
+template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     __shared__ float red[WAVES][16][64];   // 32 KiB: one accumulator tile per wave
     __shared__ float sh_inv[32];           // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
     constexpr int C = (NB == 2) ? 4 : 8;   // k-tiles per super-chunk
-    static_assert(MT == 1, "row blocks of 32");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int nt = blockIdx.x;
@@ -55,12 +55,11 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
     const int arow = g.row_off + (r < g.M ? r : g.M - 1);          // clamp: computed on valid memory, never stored
     // fragment-tiled A: this lane's 8 elements of k-tile kt sit at tile_off(arow, 16 kt + 8 h); consecutive lanes are contiguous
-    const char* abase = reinterpret_cast<const char*>(g.A) + tile_off(arow, kt_lo * 16 + h * 8, g.KT) * (NORM ? 4 : 2);
+    const s8_t* ap = reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.A) + tile_off(arow, kt_lo * 16 + h * 8, g.KT));
 
     struct Chunk {
         s8_t b[NB][C];
-        f4_t a32[NORM ? C : 1][2];
-        s8_t a16[NORM ? 1 : C];
+        s8_t a[C];
     };
     auto issue = [&](int sc, Chunk& ck) {
 #pragma unroll
@@ -69,13 +68,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
 #pragma unroll
             for (int b = 0; b < NB; ++b) ck.b[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
-            if (NORM) {
-                const f4_t* xp = reinterpret_cast<const f4_t*>(abase + (int64_t)k * 2048);
-                ck.a32[NORM ? u : 0][0] = xp[0];
-                ck.a32[NORM ? u : 0][1] = xp[1];
-            } else {
-                ck.a16[NORM ? 0 : u] = *reinterpret_cast<const s8_t*>(abase + (int64_t)k * 1024);
-            }
+            ck.a[u] = ap[(int64_t)k * 64];            // 64 lanes x 16 B = the next contiguous KiB
         }
     };
 
@@ -93,7 +86,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             if (row < g.M && n < g.N) xres[q] = g.out[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))];
         }
     }
-    if (NORM) {   // row scales: half-wave (w, h) owns rows 2w + h and 2w + h + 16, its 32 lanes split the partials
+    if (g.post_scale) {   // row scales: half-wave (w, h) owns rows 2w + h and 2w + h + 16, its 32 lanes split the partials
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row_i = 2 * w + h + 16 * rr;
@@ -107,8 +100,6 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         }
     }
     if (n_sc > 1) issue(1, c1);
-    __syncthreads();
-    const float inv = NORM ? sh_inv[r] : 1.f;
 
     f16_t acc[NB];
 #pragma unroll
@@ -119,24 +110,9 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     auto consume = [&](int sc, Chunk& ck) {
 #pragma unroll
         for (int u = 0; u < C; ++u) {
-            const int k = sc * C + u;
-            s8_t af;
-            if (NORM) {
-                const float* wn = g.norm_w + (kt_lo + (k < n_k ? k : n_k - 1)) * 16 + h * 8;
-                const f4_t w0 = *reinterpret_cast<const f4_t*>(wn), w1 = *reinterpret_cast<const f4_t*>(wn + 4);
-                const f4_t x0 = ck.a32[NORM ? u : 0][0], x1 = ck.a32[NORM ? u : 0][1];
-                i4_t pk;
-                pk[0] = (int)pk2(w0[0] * (x0[0] * inv), w0[1] * (x0[1] * inv));
-                pk[1] = (int)pk2(w0[2] * (x0[2] * inv), w0[3] * (x0[3] * inv));
-                pk[2] = (int)pk2(w1[0] * (x1[0] * inv), w1[1] * (x1[1] * inv));
-                pk[3] = (int)pk2(w1[2] * (x1[2] * inv), w1[3] * (x1[3] * inv));
-                af = __builtin_bit_cast(s8_t, pk);
-            } else {
-                af = ck.a16[NORM ? 0 : u];
-            }
-            if (k < n_k) {
+            if (sc * C + u < n_k) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = mfma32(af, ck.b[b][u], acc[b]);
+                for (int b = 0; b < NB; ++b) acc[b] = mfma32(ck.a[u], ck.b[b][u], acc[b]);
             }
         }
     };
@@ -172,7 +148,8 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         const int i = (tid + q * 512) >> 6;
         const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
         const bool ok = row < g.M && n < g.N;
-        float v = val[0][q];
+        const float inv = g.post_scale ? sh_inv[row & 31] : 1.f;     // (sh_inv was published before the reduce barriers)
+        float v = val[0][q] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
                 if (g.bias) v += g.bias[n];
@@ -184,7 +161,9 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
                 if (g.bias) v += g.bias[n];
                 if (g.scale) v *= g.scale[n];
                 xn = xres[q] + v;
-                g.out[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))] = xn;
+                const int64_t o = tile_off(g.row_off + row, n, (int)(g.ldc >> 4));
+                g.out[o] = xn;
+                if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(g.next_norm_w[n] * xn);   // operand of the GEMM behind the next RMSNorm
             }
             float sq = xn * xn;                   // half-wave = one row's 32 columns
 #pragma unroll
@@ -192,30 +171,28 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)(g.row_off + row) * g.rowsq_out_n + nt] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
-                const float u = val[NB - 1][q];
+                const float u = val[NB - 1][q] * inv;
                 g.out_bf16[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
             }
         }
     }
 }
 
-template <int MT, bool NORM>
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     if (!e0 && !e1) {   // plain launches are what a stream capture records
         switch (g.epi) {
-            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(512), 0, ctx->stream, g); break;
-            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(512), 0, ctx->stream, g); break;
-            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(512), 0, ctx->stream, g); break;
+            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<COL_STORE>), grid, dim3(512), 0, ctx->stream, g); break;
+            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<COL_RESID>), grid, dim3(512), 0, ctx->stream, g); break;
+            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<COL_SILU>), grid, dim3(512), 0, ctx->stream, g); break;
             default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
         }
-        RT_HIP(ctx, hipGetLastError());
-        return RT_OK;
-    }
-    switch (g.epi) {
-        case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_STORE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_RESID>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-        case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<MT, NORM, COL_SILU>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-        default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
+    } else {            // device-side begin/end stamps for the roofline figure
+        switch (g.epi) {
+            case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<COL_STORE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+            case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<COL_RESID>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+            case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<COL_SILU>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
+            default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
+        }
     }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -240,7 +217,7 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
         g.N = w.N;
     }
     if (g.epi == COL_RESID && (!g.rowsq_out || g.rowsq_out_n < g.NT)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: rowsq_out too small");
-    if (g.a_norm && (!g.rowsq || !g.norm_w || g.rowsq_n < 1)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: norm prologue without partials");
-    dim3 grid(tiles);
-    return g.a_norm ? dispatch_epi<1, true>(ctx, g, grid, ev_start, ev_stop) : dispatch_epi<1, false>(ctx, g, grid, ev_start, ev_stop);
+    if (g.post_scale && (!g.rowsq || g.rowsq_n < 1)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: row scaling without partials");
+    if (g.next_bf16 && !g.next_norm_w) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: next operand without its norm weight");
+    return dispatch_epi(ctx, g, dim3(tiles), ev_start, ev_stop);
 }

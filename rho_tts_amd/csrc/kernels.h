@@ -70,15 +70,16 @@ enum { COL_STORE = 0, COL_RESID = 1, COL_SILU = 2 };
 struct ColArgs {
     // All activations of the column path are fragment-tiled (common.h tile_off); STORE outputs stay row-major.
     int row_off = 0;                // first row (in the tiled A / x / act buffers) of this 32-row block
-    const void* A = nullptr;        // tiled bf16 [rows][K], or the tiled f32 residual stream when a_norm
-    int a_norm = 0;                 // 1: A is f32; apply rsqrt(sum(rowsq)/K + eps) * norm_w while loading
-    const float* rowsq = nullptr;   // [M][rowsq_n] partial sums of squares of A's rows
+    const void* A = nullptr;        // tiled bf16 [rows][K]; behind an RMSNorm it holds bf16(norm_w .* x)
+    int post_scale = 0;             // 1: multiply the accumulator rows by rsqrt(sum(rowsq)/K + eps)  (the RMSNorm row scale)
+    const float* rowsq = nullptr;   // [rows][rowsq_n] partial sums of squares of x's rows
     int rowsq_n = 0;
     float eps = 0.f;
-    const float* norm_w = nullptr;  // [K]
     int M = 0, K = 0;
     int epi = COL_STORE;
-    float* out = nullptr;           // STORE: out [M][ldc] f32;  RESID: residual stream, updated in place
+    float* out = nullptr;           // STORE: out [M][ldc] f32 row-major;  RESID: tiled f32 residual stream, updated in place
+    bf16_t* next_bf16 = nullptr;    // RESID: tiled bf16(next_norm_w .* x_new), the operand of the GEMM behind the next RMSNorm
+    const float* next_norm_w = nullptr;
     int64_t ldc = 0;
     const float* bias = nullptr;    // [N] optional
     const float* scale = nullptr;   // [N] optional (layer scale), RESID only
@@ -91,7 +92,8 @@ struct ColArgs {
 };
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)
-int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr);
+int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr,
+                 bf16_t* a_tiled = nullptr, const float* norm_w = nullptr);
 
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):

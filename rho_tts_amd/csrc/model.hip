@@ -364,10 +364,12 @@ struct DecWs {
     bf16_t* act = nullptr;  // [M][inter]
     float* q = nullptr;     // [M][q_dim] (only for passes with several rows per slot)
     float* xT = nullptr;    // fragment-tiled residual stream [ceil(M/32)*32][H]
+    bf16_t* xa = nullptr;   // fragment-tiled bf16(norm_w .* x): operand of the GEMM behind the next RMSNorm
 };
 int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
     const size_t Mp = (size_t)(M + 31) / 32 * 32;     // tiled buffers hold whole 32-row blocks
     RT_TRY(pool_arr(m, Mp * d.hidden, &w->xT));
+    RT_TRY(pool_arr(m, Mp * d.hidden, &w->xa));
     RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
     RT_TRY(pool_arr(m, (size_t)M * (d.heads + 2 * d.kv_heads) * d.head_dim, &w->qkv));
     RT_TRY(pool_arr(m, Mp * d.heads * d.head_dim, &w->ao));
@@ -395,8 +397,9 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
     const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
     for (int i = 0; i < d.layers; ++i) {
         LayerW& L = S.L[i];
-        ColArgs a;
-        a.A = x; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.norm_w = L.ln1; a.M = M; a.K = H;
+        const float* next_w = (i + 1 < d.layers) ? S.L[i + 1].ln1 : S.norm;   // the norm that reads x after this layer
+        ColArgs a;      // qkv = rmsnorm(x; ln1) Wqkv^T : operand w.xa = bf16(ln1 .* x), row scale from rowsq
+        a.A = w.xa; a.post_scale = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.M = M; a.K = H;
         a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw;
         RT_TRY(col_gemm(m, a, L.wqkv));
         if (one_row_per_slot) {
@@ -407,27 +410,28 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
                                    pos_add, w.q, S.kv, i, frame_ptr));
             RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1));
         }
-        ColArgs o;
+        ColArgs o;      // x += ls1 .* (ao Wo^T); emits rowsq and bf16(ln2 .* x) for the MLP
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
-        o.rowsq_out = rowsq; o.rowsq_out_n = NTh;
+        o.rowsq_out = rowsq; o.rowsq_out_n = NTh; o.next_bf16 = w.xa; o.next_norm_w = L.ln2;
         RT_TRY(col_gemm(m, o, L.wo));
-        ColArgs gu;
-        gu.A = x; gu.a_norm = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.norm_w = L.ln2; gu.M = M; gu.K = H;
+        ColArgs gu;     // act = silu(g) * u with [g; u] = rmsnorm(x; ln2) Wgu^T
+        gu.A = w.xa; gu.post_scale = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.M = M; gu.K = H;
         gu.epi = COL_SILU; gu.out_bf16 = w.act; gu.ldc = d.inter;
         RT_TRY(col_gemm(m, gu, L.wgu));
-        ColArgs dn;
+        ColArgs dn;     // x += ls2 .* (act Wd^T); emits rowsq and bf16(next norm .* x)
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
-        dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh;
+        dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w;
         RT_TRY(col_gemm(m, dn, L.wd));
     }
     return RT_OK;
 }
 // out[M][N] = rmsnorm(x) W^T (+ bias): LM heads and the mtp projection, final norm applied in the GEMM prologue
-// x is the fragment-tiled residual stream; rows [row_off, row_off + M) are read, out rows 0.. are written row-major
-int col_head(rt_model* m, const float* xT, const float* rowsq, int rowsq_n, int row_off, int M, int K, const float* norm_w, float eps,
+// xa = tiled bf16(final_norm_w .* x) as left by the stack's last down-projection (or by k_rowsq when the stack has not run yet);
+// rows [row_off, row_off + M) are read, out rows 0.. are written row-major
+int col_head(rt_model* m, const bf16_t* xa, const float* rowsq, int rowsq_n, int row_off, int M, int K, float eps,
              const PackedW& W, const float* bias, float* out) {
     ColArgs a;
-    a.A = xT; a.a_norm = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.norm_w = norm_w; a.M = M; a.K = K; a.row_off = row_off;
+    a.A = xa; a.post_scale = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.M = M; a.K = K; a.row_off = row_off;
     a.epi = COL_STORE; a.out = out - (size_t)row_off * W.N; a.ldc = W.N; a.bias = bias;
     return col_gemm(m, a, W);
 }
@@ -886,7 +890,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(alloc_dec_ws(m, c.predictor, B2, &dwp));
         // xt <- residual-stream rows (before the final norm) of each item's last prompt position
         RT_TRY(launch_gather_f32(ctx, x_all, H, d_last, B, xt, nullptr));
-        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT));
+        // (the prompt's last rows are already the talker's OUTPUT: their next consumer is the final norm)
+        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT, dwt.xa, m->talker.norm));
     } else {
         // hn <- final-norm rows of each item's last prompt position
         RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
@@ -907,7 +912,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // is base + *d_frame * stride resolved on the device, so the same launches (or one captured graph) serve every frame.
     auto enqueue_a = [&]() -> int {
         int ns = 0;
-        if (col) { RT_TRY(col_head(m, dwt.xT, rowsq_t, NTt, 0, B, H, m->talker.norm, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
+        if (col) { RT_TRY(col_head(m, dwt.xa, rowsq_t, NTt, 0, B, H, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
         else RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
         SampleArgs sa{};
         sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
@@ -922,7 +927,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(launch_sample(ctx, sa));
         // predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
-            if (col) RT_TRY(col_head(m, dwt.xT, rowsq_t, NTt, 0, B, H, m->talker.norm, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
+            if (col) RT_TRY(col_head(m, dwt.xa, rowsq_t, NTt, 0, B, H, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
             else {
                 RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
                 RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
@@ -933,7 +938,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_codes, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
         }
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp, dwp.xT));
+            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp, dwp.xT, dwp.xa, m->pred.L[0].ln1));
             RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B2, d_slot_b, d_pos_p2, 0, false));
         } else {
             RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
@@ -941,7 +946,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         for (int q = 0; q < G - 1; ++q) {
             const size_t roff = (q == 0) ? (size_t)B : 0;      // the first head reads the rows of position 1
             if (col) {
-                RT_TRY(col_head(m, dwp.xT, rowsq_p, NTp, (int)roff, B, Hp, m->pred.norm, c.predictor.rms_eps,
+                RT_TRY(col_head(m, dwp.xa, rowsq_p, NTp, (int)roff, B, Hp, c.predictor.rms_eps,
                                 PW(m, "pred.head" + std::to_string(q)), nullptr, logits));
                 ns = 1;
             } else {
@@ -962,7 +967,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_codes + q + 1, B, xp, nullptr, G, d_frame, codes_fs));
                 else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_codes + q + 1, B, H, nullptr, nullptr, nullptr, xp, nullptr, G, d_frame, codes_fs));
                 if (col) {
-                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp, dwp.xT));
+                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp, dwp.xT, dwp.xa, m->pred.L[0].ln1));
                     RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
                 } else {
                     RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
@@ -975,7 +980,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     auto enqueue_b = [&]() -> int {
         RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_codes, B, H, pad_t, nullptr, nullptr, xt, nullptr, G, d_frame, codes_fs));
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT));
+            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT, dwt.xa, m->talker.L[0].ln1));
             RT_TRY(stack_decode(m, m->talker, dwt, dwt.xT, rowsq_t, B, d_slot_b, d_pos_b, 0, true, d_frame));
         } else {
             RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, 0, hn, hn_f32, d_frame));
@@ -994,7 +999,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         for (const void* p : {(const void*)xt, (const void*)xp, (const void*)logits, (const void*)d_codes, (const void*)d_eos, (const void*)d_seen,
                               (const void*)d_forced, (const void*)A->d_trace_talker, (const void*)A->d_trace_predictor, (const void*)pad_t,
                               (const void*)d_frame, (const void*)d_seed, (const void*)d_items, (const void*)d_slot_b, (const void*)d_pos_b,
-                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.xT, (const void*)dwp.xT, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
+                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.xT, (const void*)dwp.xT, (const void*)dwt.xa, (const void*)dwp.xa, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
                               (const void*)dwp.act, (const void*)wt.slabs, (const void*)wp.slabs, (const void*)hn, (const void*)hn_p,
                               (const void*)ctx->stream})
             mix((uint64_t)(uintptr_t)p);

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int 
 // rowsq[row][0] = sum x^2, rowsq[row][1..n) = 0: seeds the NORM prologue of the column-owner GEMM; optionally also
 // re-tiles the row into the fragment layout (common.h tile_off) the decode GEMMs read.
 __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int H, float* __restrict__ rowsq, int rowsq_n,
-                                               float* __restrict__ x_tiled) {
+                                               float* __restrict__ x_tiled, bf16_t* __restrict__ a_tiled,
+                                               const float* __restrict__ norm_w) {
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
     const f4_t* xr = reinterpret_cast<const f4_t*>(x + row * H);
@@ -81,6 +82,13 @@ __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int 
         const f4_t v = xr[i];
         ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         if (x_tiled) *reinterpret_cast<f4_t*>(x_tiled + tile_off((int)row, i * 4, H >> 4)) = v;
+        if (a_tiled) {   // bf16(norm_w .* x): the first GEMM's operand (its row scale is applied after the product)
+            const f4_t wv = reinterpret_cast<const f4_t*>(norm_w)[i];
+            uint2 pk;
+            pk.x = f32x2_to_bf16x2(wv[0] * v[0], wv[1] * v[1]);
+            pk.y = f32x2_to_bf16x2(wv[2] * v[2], wv[3] * v[3]);
+            *reinterpret_cast<uint2*>(a_tiled + tile_off((int)row, i * 4, H >> 4)) = pk;
+        }
     }
     const float tot = block_sum_f32(ss, sh);
     for (int j = threadIdx.x; j < rowsq_n; j += 256) rowsq[row * rowsq_n + j] = j == 0 ? tot : 0.f;
@@ -305,9 +313,10 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
     return RT_OK;
 }
 
-int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled) {
+int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled, bf16_t* a_tiled,
+                 const float* norm_w) {
     if (M <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled);
+    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
