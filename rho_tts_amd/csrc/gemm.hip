@@ -384,13 +384,14 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 v += bias;
                 if (e.act == ACT_SILU) v = v / (1.f + __expf(-v));
                 else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                else if (e.act == ACT_SNAKE) { const float s = sinf(v * sa); v = v + sib * s * s; }
+                else if (e.act == ACT_SNAKE) { const float s = __sinf(v * sa); v = v + sib * s * s; }
+                else if (e.act == ACT_CLAMP1) v = fminf(1.f, fmaxf(-1.f, v));
                 v *= scale;
                 if (e.residual) v += e.residual[o];
                 if (e.out_f32) e.out_f32[o] = v;
                 if (e.out_bf16) e.out_bf16[o] = f32_to_bf16(v);
                 if (e.out2_bf16 || e.out2_f32) {
-                    const float s = sinf(v * s2a);
+                    const float s = __sinf(v * s2a);
                     const float v2 = v + s2ib * s * s;
                     if (e.out2_bf16) e.out2_bf16[o] = f32_to_bf16(v2);
                     if (e.out2_f32) e.out2_f32[o] = v2;

@@ -30,7 +30,7 @@ struct GemmA {
     int rows_in = 0;       // input rows per batch item
 };
 
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SNAKE = 3 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SNAKE = 3, ACT_CLAMP1 = 4 };
 
 // out = (act(acc + bias)) * scale + residual, optionally also out2 = snake2(out) in bf16.
 // All per-column vectors have length N.  With split_k > 1 only raw f32 partial slabs are written

@@ -240,7 +240,7 @@ void declare_slots(rt_model* m) {
     const int cl = m->dec_ch.back();
     add_slot(m, "codec.fin_a", K_VEC, cl, 1);
     add_slot(m, "codec.fin_ib", K_VEC, cl, 1);
-    add_slot(m, "codec.fin_w", K_VEC, 7 * (int64_t)cl, 1);
+    add_slot(m, "codec.fin_w", K_GEMM, 1, 7 * (int64_t)cl);   // last conv (C -> 1, k = 7) as a one-column GEMM
     add_slot(m, "codec.fin_b", K_VEC, 1, 1);
 }
 
@@ -1205,10 +1205,15 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
     }
     float* wav_tmp = nullptr;
     RT_TRY(pool_arr(m, (size_t)B * Tc, &wav_tmp));
-    float fin_b = 0.f;
-    RT_HIP(ctx, hipMemcpyAsync(&fin_b, VEC(m, "codec.fin_b"), 4, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RT_TRY(launch_final_conv(ctx, s_in, B, (int)Tc, m->dec_ch.back(), VEC(m, "codec.fin_w"), fin_b, wav_tmp));
+    {
+        // last conv: channels -> 1, k = 7, causal, then clamp(-1, 1): the 7 x C taps of one output sample are contiguous
+        // in the channels-last buffer, so it is the same implicit GEMM with a single output column
+        const int cl = m->dec_ch.back();
+        GemmA a; a.ptr = s_in; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = cl; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
+        a.rows_out = (int)Tc; a.rows_in = (int)Tc;
+        GemmEpi e; e.bias = VEC(m, "codec.fin_b"); e.act = ACT_CLAMP1; e.out_f32 = wav_tmp; e.ldc = 1;
+        RT_TRY(launch_gemm(ctx, a, PW(m, "codec.fin_w"), e));
+    }
     RT_HIP(ctx, hipMemcpy2DAsync(d_wav, (size_t)wav_stride * 4, wav_tmp, (size_t)Tc * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < B; ++b) h_wav_len[b] = rt_wav_length(m, h_n_frames[b]);
