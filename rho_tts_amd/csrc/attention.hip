@@ -19,14 +19,17 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
                                                    int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                    int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
-                                                   const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled) {
+                                                   const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled, int prefix_slot,
+                                                   int prefix_len) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
     __shared__ float sh[4][REP][LPP][10];
     __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
 
-    const int row = blockIdx.x, kh = blockIdx.y;
+    // x = kv head (fastest): workgroups are dealt round-robin over the 8 XCDs, so with 8 kv heads every XCD's L2 holds
+    // ONE head's shared-prefix K/V and serves it to all the rows of that head
+    const int kh = blockIdx.x, row = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane % LPP, pg = lane / LPP;
     const int hi = row_pos[row] + pos_add + (frame_ptr ? *frame_ptr : 0);
@@ -90,6 +93,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
     const bf16_t* kb = kc + base * D + sub * 8;
     const bf16_t* vb = vc + base * D + sub * 8;
+    // rows below prefix_len come from the shared prefix slot (same bytes for every sequence -> cache hits)
+    const int64_t pdelta = prefix_slot >= 0 ? (((int64_t)prefix_slot - slot) * kv_heads * max_pos) * D : 0;
 
     for (int p0 = lo + w * PPW + pg; p0 <= hi; p0 += 4 * PPW * U) {
         u4_t kk[U], vv[U];
@@ -97,8 +102,9 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
         for (int u = 0; u < U; ++u) {
             const int p = p0 + u * 4 * PPW;
             const int pc = p <= hi ? p : hi;
-            kk[u] = *reinterpret_cast<const u4_t*>(kb + (int64_t)pc * D);
-            vv[u] = *reinterpret_cast<const u4_t*>(vb + (int64_t)pc * D);
+            const int64_t po = (int64_t)pc * D + (pc < prefix_len ? pdelta : 0);
+            kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
+            vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -169,15 +175,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     }
 }
 
-struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; };
+struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len; };
 
 template <int D, bool FUSED>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -186,13 +192,16 @@ int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int
 
 template <bool FUSED>
 int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot, const int32_t* row_pos,
-                  int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const FusedArgs& f) {
+                  int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const FusedArgs& f0) {
     if (M <= 0) return RT_OK;
+    FusedArgs f = f0;
+    f.prefix_slot = kv.prefix_slot;
+    f.prefix_len = kv.prefix_slot >= 0 ? kv.prefix_len : 0;
     if (heads % kv_heads) return rt_fail(ctx, RT_ERR_INVALID, "attention: heads %d not a multiple of kv_heads %d", heads, kv_heads);
     const int rep = heads / kv_heads;
     bf16_t* kc = kv.k + layer * kv.layer_stride();
     bf16_t* vc = kv.v + layer * kv.layer_stride();
-    dim3 grid(M, kv_heads);
+    dim3 grid(kv_heads, M);
     switch (head_dim) {
         case 32: return dispatch_rep<32, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
         case 64: return dispatch_rep<64, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
@@ -215,6 +224,6 @@ int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int 
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
                            const int32_t* frame_ptr, int out_tiled) {
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled};
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

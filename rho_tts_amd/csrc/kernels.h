@@ -111,6 +111,9 @@ struct KvCache {
     bf16_t* k = nullptr;   // [layers][slots][kv_heads][max_pos][head_dim]
     bf16_t* v = nullptr;
     int layers = 0, slots = 0, kv_heads = 0, max_pos = 0, head_dim = 0;
+    // Shared voice prefix: cache rows [0, prefix_len) of EVERY sequence are read from slot `prefix_slot` (one copy in HBM,
+    // served from L2 / Infinity Cache to all the workgroups that re-read it) instead of a per-sequence copy.  -1 = off.
+    int prefix_slot = -1, prefix_len = 0;
     size_t layer_stride() const { return (size_t)slots * kv_heads * max_pos * head_dim; }
 };
 // qkv slabs [S][M][(heads+2*kv_heads)*d] -> q (f32 [M][heads][d], normed + roped), k/v appended to the cache

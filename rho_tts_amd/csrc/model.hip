@@ -678,6 +678,7 @@ int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, c
             if (id >= (q == 0 ? c.codec_vocab : c.predictor_vocab)) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_voice: codec id %d out of range", id);
         }
     }
+    m->talker.kv.prefix_slot = -1;    // the prefix slot attends to itself while it is being computed
     pool_release_all(m);
     // text side: project every row that has a text id (rows without one get -1 -> no text term... they get tts_pad by contract)
     int32_t *d_tid = nullptr, *d_cid = nullptr, *d_slot = nullptr, *d_pos = nullptr;
@@ -780,13 +781,9 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: predictor sampling needs 1 <= top_k <= 64 and temperature > 0");
     pool_release_all(m);
 
-    // ---- fan the voice prefix KV out to the B sequence slots
-    {
-        KvCache& kv = m->talker.kv;
-        hipLaunchKernelGGL(k_kv_fanout, dim3(c.talker.layers * c.talker.kv_heads, B), dim3(256), 0, ctx->stream, kv.k, kv.v,
-                           (int64_t)kv.layer_stride(), c.talker.kv_heads, kv.max_pos, c.talker.head_dim, m->prefix_slot(), Lp);
-        RT_HIP(ctx, hipGetLastError());
-    }
+    // ---- the voice prefix KV stays in its own slot: every sequence reads cache rows [0, Lp) from there (KvCache::prefix_slot)
+    m->talker.kv.prefix_slot = m->prefix_slot();
+    m->talker.kv.prefix_len = Lp;
     // ---- suffix rows: [text tokens + tts_eos] x codec_pad, then (tts_pad, codec_bos)
     std::vector<int32_t> s_tid(n_suffix + 1), s_cid((size_t)n_suffix * G, -1), s_slot(n_suffix), s_pos(n_suffix), last_row(B), P(B);
     int r = 0;
