@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--tune", default="", help="comma-separated rt_debug_tune codes (100/101 legacy/column decode, 200/201 eager/graph)")
     args = ap.parse_args()
 
@@ -78,10 +79,16 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        n_dev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist_mod.init_process_group(backend=args.backend, rank=rank, world_size=world)
+            local_rank = local_rank % max(1, n_dev)           # rehearsal: several ranks may share a GPU
         dist = dist_mod
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    comm_dev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")
 
     from rho_tts_amd import _native, config
     from rho_tts_amd.engine import Engine
@@ -108,12 +115,12 @@ def main():
         if dist is None or rank == 0:
             eng.set_voice(cond)                                   # conditioning: voice-prefix prefill, once per step
         if dist is not None:
-            broadcast_voice(eng, dist, src=0)
+            broadcast_voice(eng, dist, src=0, comm_device=comm_dev)
         raw = eng.synthesize(texts, seed=789, item_ids=item_ids)
         outs, stats = eng.post_process([[w] for w in raw], post)
         audio_s = sum(w.numel() for w in raw) / cfg.sample_rate
         if dist is not None:
-            host = gather_waveforms(outs, dist, dst=0, device=dev)
+            host = gather_waveforms(outs, dist, dst=0, device=comm_dev)
         else:
             host = [o.cpu() for o in outs]
         return audio_s, host
@@ -138,7 +145,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
-    t = torch.tensor([dt, audio_local], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, audio_local], dtype=torch.float64, device=comm_dev)
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -158,7 +165,7 @@ def main():
         eng.model.profile(False)
         if n_l > 0 and ms > 0:
             achieved = by / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_gemm_skinny", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "k_gemm_col", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": None, "launches": int(n_l),
                     "avg_launch_us": round(ms * 1e3 / n_l, 3), "avg_bytes_per_launch": round(by / n_l, 1)}
         # decode-step view: algorithmic bytes per frame for the local batch

@@ -28,20 +28,21 @@ def shard_items(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(x) for x in out]
 
 
-def broadcast_voice(engine, dist, src: int = 0) -> None:
-    """Rank ``src`` has computed the voice prefix (Engine.set_voice); every other rank imports its KV blob."""
+def broadcast_voice(engine, dist, src: int = 0, comm_device=None) -> None:
+    """Rank ``src`` has computed the voice prefix (Engine.set_voice); every other rank imports its KV blob.
+    ``comm_device``: where the collective runs (the GPU for RCCL; "cpu" to rehearse on gloo)."""
     rank = dist.get_rank()
-    dev = engine.device
+    dev = comm_device or engine.device
     meta = torch.zeros(2, dtype=torch.int64, device=dev)
     if rank == src:
-        blob = engine.model.export_voice()
+        blob = engine.model.export_voice().to(dev)
         meta[0], meta[1] = engine.model.prefix_len(), blob.numel()
     dist.broadcast(meta, src=src)
     if rank != src:
         blob = torch.empty(int(meta[1]), dtype=torch.bfloat16, device=dev)
     dist.broadcast(blob, src=src)
     if rank != src:
-        engine.model.import_voice(int(meta[0]), blob)
+        engine.model.import_voice(int(meta[0]), blob.to(engine.device))
 
 
 def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=None) -> Optional[List[List[torch.Tensor]]]:
