@@ -43,6 +43,9 @@ def broadcast_voice(engine, dist, src: int = 0, comm_device=None) -> None:
     dist.broadcast(blob, src=src)
     if rank != src:
         engine.model.import_voice(int(meta[0]), blob.to(engine.device))
+        if getattr(engine, "voice", None) is None:          # the conditioning now lives in the imported prefix KV
+            from .voice import VoiceConditioning
+            engine.voice = VoiceConditioning("(imported)", None, None, [], None)
 
 
 def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=None) -> Optional[List[List[torch.Tensor]]]:
