@@ -93,6 +93,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 300) { g_pred_nt = skinny_variant - 300; return RT_OK; }               // 300: predictor weights cacheable, 301: nt
     if (skinny_variant >= 200) { g_use_graph = skinny_variant - 200; return RT_OK; }            // 200: eager frames, 201: graph replay
     if (skinny_variant >= 100) { g_decode_col = skinny_variant - 100; return RT_OK; }   // 100: legacy 9-launch decode, 101: column path
     if (skinny_variant >= 0) g_skinny_variant = skinny_variant;

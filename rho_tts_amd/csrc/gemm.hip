@@ -419,6 +419,7 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
     return RT_OK;
 }
 
+int g_pred_nt = 0;              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
 int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
 int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
 int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             int k = sc * C + u;
             if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
 #pragma unroll
-            for (int b = 0; b < NB; ++b) ck.b[b][u] = __builtin_nontemporal_load(wp[b] + (int64_t)k * 64);
+            for (int b = 0; b < NB; ++b) ck.b[b][u] = g.nt ? __builtin_nontemporal_load(wp[b] + (int64_t)k * 64) : wp[b][(int64_t)k * 64];
             ck.a[u] = ap[(int64_t)k * 64];            // 64 lanes x 16 B = the next contiguous KiB
         }
     };

@@ -62,6 +62,7 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
 int skinny_pick_split(int M, int N, int K, int n_cu);
 extern int g_decode_col;
 extern int g_use_graph;
+extern int g_pred_nt;
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
 extern int g_skinny_waves_per_cu;
 
@@ -71,6 +72,8 @@ struct ColArgs {
     // All activations of the column path are fragment-tiled (common.h tile_off); STORE outputs stay row-major.
     int row_off = 0;                // first row (in the tiled A / x / act buffers) of this 32-row block
     const void* A = nullptr;        // tiled bf16 [rows][K]; behind an RMSNorm it holds bf16(norm_w .* x)
+    int nt = 1;                     // 1: stream the weights with non-temporal loads (read once per step); 0: let them stay in the
+                                    //    Infinity Cache (the 220 MB predictor is re-read 15 times per frame)
     int post_scale = 0;             // 1: multiply the accumulator rows by rsqrt(sum(rowsq)/K + eps)  (the RMSNorm row scale)
     const float* rowsq = nullptr;   // [rows][rowsq_n] partial sums of squares of x's rows
     int rowsq_n = 0;

@@ -377,9 +377,10 @@ int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
     return RT_OK;
 }
 // Row blocks of 32: a 64-row pass (the predictor's first, 2 rows per sequence) streams the weights twice.
-int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W) {
+int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor = false) {
     for (int r0 = 0; r0 < a0.M; r0 += 32) {
         ColArgs a = a0;
+        a.nt = is_predictor ? g_pred_nt : 1;
         a.M = std::min(32, a0.M - r0);
         a.row_off = a0.row_off + r0;
         hipEvent_t e0, e1;
@@ -395,13 +396,14 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
+    const bool isp = &S == &m->pred;
     for (int i = 0; i < d.layers; ++i) {
         LayerW& L = S.L[i];
         const float* next_w = (i + 1 < d.layers) ? S.L[i + 1].ln1 : S.norm;   // the norm that reads x after this layer
         ColArgs a;      // qkv = rmsnorm(x; ln1) Wqkv^T : operand w.xa = bf16(ln1 .* x), row scale from rowsq
         a.A = w.xa; a.post_scale = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.M = M; a.K = H;
         a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw;
-        RT_TRY(col_gemm(m, a, L.wqkv));
+        RT_TRY(col_gemm(m, a, L.wqkv, isp));
         if (one_row_per_slot) {
             RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
                                           pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1));
@@ -413,15 +415,15 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         ColArgs o;      // x += ls1 .* (ao Wo^T); emits rowsq and bf16(ln2 .* x) for the MLP
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
         o.rowsq_out = rowsq; o.rowsq_out_n = NTh; o.next_bf16 = w.xa; o.next_norm_w = L.ln2;
-        RT_TRY(col_gemm(m, o, L.wo));
+        RT_TRY(col_gemm(m, o, L.wo, isp));
         ColArgs gu;     // act = silu(g) * u with [g; u] = rmsnorm(x; ln2) Wgu^T
         gu.A = w.xa; gu.post_scale = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.M = M; gu.K = H;
         gu.epi = COL_SILU; gu.out_bf16 = w.act; gu.ldc = d.inter;
-        RT_TRY(col_gemm(m, gu, L.wgu));
+        RT_TRY(col_gemm(m, gu, L.wgu, isp));
         ColArgs dn;     // x += ls2 .* (act Wd^T); emits rowsq and bf16(next norm .* x)
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
         dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w;
-        RT_TRY(col_gemm(m, dn, L.wd));
+        RT_TRY(col_gemm(m, dn, L.wd, isp));
     }
     return RT_OK;
 }
