@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
             at += sh[ww][r][sb][2 + j] * c;
         }
         const int kcol = (kh * REP + r) * D + sb * 8 + j;
-        const int64_t oo = out_tiled ? tile_off(row, kcol, (heads * D) >> 4) : (int64_t)row * heads * D + kcol;
+        const int64_t oo = out_tiled ? tile_off(row, kcol, heads * D) : (int64_t)row * heads * D + kcol;
         out[oo] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
     }
 }

@@ -74,11 +74,11 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 
 // Fragment-tiled activation layout shared by the decode kernels: a [rows][K] matrix is stored as
-// [row block of 32][k tile of 16][lane = (k half << 5) | row][8 elements], i.e. exactly the A-operand order of
-// v_mfma_f32_32x32x16_bf16, so a wave fetches an operand tile with ONE fully coalesced load instead of 32 row-strided
-// pieces.  KT = K / 16.
-__host__ __device__ __forceinline__ int64_t tile_off(int m, int k, int KT) {
-    return ((((int64_t)(m >> 5) * KT + (k >> 4)) * 64 + ((((k >> 3) & 1) << 5) | (m & 31))) << 3) + (k & 7);
+// [row block of 16][k tile of 32][lane = (k octet << 4) | row][8 elements], i.e. exactly the A-operand order of
+// v_mfma_f32_16x16x32_bf16, so a wave fetches an operand tile with ONE fully coalesced 1-KiB load instead of 16
+// row-strided pieces.  K % 32 == 0.
+__host__ __device__ __forceinline__ int64_t tile_off(int m, int k, int K) {
+    return ((((int64_t)(m >> 4) * (K >> 5) + (k >> 5)) * 64 + ((((k >> 3) & 3) << 4) | (m & 15))) << 3) + (k & 7);
 }
 
 // bf16 <-> f32 (round-to-nearest-even, NaN preserved by the hardware cast on gfx950)

@@ -151,27 +151,27 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     RT_HIP(ctx, hipMalloc(&a, (size_t)32 * K * 4));
     RT_HIP(ctx, hipMalloc((void**)&out, (size_t)32 * N * 4));
     RT_HIP(ctx, hipMalloc((void**)&act, (size_t)32 * N * 2));
-    RT_HIP(ctx, hipMalloc((void**)&rowsq, (size_t)32 * 256 * 4));
-    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)32 * (N / 32 + 1) * 4));
+    RT_HIP(ctx, hipMalloc((void**)&rowsq, (size_t)32 * 512 * 4));
+    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)32 * (N / 16 + 1) * 4));
     RT_HIP(ctx, hipMalloc((void**)&normw, (size_t)std::max(K, N) * 4));
     RT_HIP(ctx, hipMemsetAsync(wbuf, 0x3c, pb * n_mats, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(a, 0x3c, (size_t)32 * K * 4, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(out, 0, (size_t)32 * N * 4, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(rowsq, 0x3c, (size_t)32 * 256 * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(rowsq, 0x3c, (size_t)32 * 512 * 4, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(normw, 0x3c, (size_t)std::max(K, N) * 4, ctx->stream));
     PackedW pw;
-    pw.N = N; pw.K = K; pw.Np = (N + 31) / 32 * 32; pw.Kp = K;
+    pw.N = N; pw.K = K; pw.Np = (N + 31) / 32 * 32; pw.Kp = K; pw.Np16 = (N + 15) / 16 * 16;
     ColArgs c;
-    c.A = a; c.post_scale = a_norm; c.rowsq = rowsq; c.rowsq_n = K / 32; c.eps = 1e-6f; c.M = M; c.K = K; c.epi = epi;
+    c.A = a; c.post_scale = a_norm; c.rowsq = rowsq; c.rowsq_n = K / 16; c.eps = 1e-6f; c.M = M; c.K = K; c.epi = epi;
     c.next_bf16 = epi == COL_RESID ? act : nullptr; c.next_norm_w = normw;
-    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.rowsq_out = rowsq_out; c.rowsq_out_n = N / 32; c.out_bf16 = act;
+    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.rowsq_out = rowsq_out; c.rowsq_out_n = N / 16; c.out_bf16 = act;
     hipEvent_t e0, e1;
     RT_HIP(ctx, hipEventCreate(&e0));
     RT_HIP(ctx, hipEventCreate(&e1));
     int rc = RT_OK;
-    for (int i = 0; i < n_mats && !rc; ++i) { pw.data = wbuf + (pb / 2) * i; rc = launch_gemm_col(ctx, c, pw); }
+    for (int i = 0; i < n_mats && !rc; ++i) { pw.data16 = wbuf + (pb / 2) * i; rc = launch_gemm_col(ctx, c, pw); }
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters && !rc; ++i) { pw.data = wbuf + (pb / 2) * (i % n_mats); rc = launch_gemm_col(ctx, c, pw); }
+    for (int i = 0; i < iters && !rc; ++i) { pw.data16 = wbuf + (pb / 2) * (i % n_mats); rc = launch_gemm_col(ctx, c, pw); }
     RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;

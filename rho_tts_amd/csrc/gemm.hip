@@ -45,6 +45,23 @@ __global__ void k_pack_weight(const bf16_t* __restrict__ src, int N, int K, int 
     }
 }
 
+__global__ void k_pack_weight16(const bf16_t* __restrict__ src, int N, int K, int Np, bf16_t* __restrict__ dst) {
+    const int KT = K / 32;
+    const int64_t n_pieces = (int64_t)(Np / 16) * KT * 64;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pieces; p += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(p & 63);
+        const int64_t tile = p >> 6;
+        const int kt = (int)(tile % KT);
+        const int nt = (int)(tile / KT);
+        const int n = nt * 16 + (lane & 15);
+        const int k0 = kt * 32 + (lane >> 4) * 8;
+        bf16_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = n < N ? src[(int64_t)n * K + k0 + j] : (bf16_t)0;
+        *reinterpret_cast<s8_t*>(dst + p * 8) = *reinterpret_cast<s8_t*>(v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- skinny
 // grid.x = Np/32 n-tiles (one wave each, 4 waves per workgroup), grid.y = split_k.
 template <int MT>
@@ -405,6 +422,21 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
 size_t packed_bytes(int N, int K) {
     const size_t Np = (size_t)(N + 31) / 32 * 32, Kp = (size_t)(K + 15) / 16 * 16;
     return Np * Kp * 2;
+}
+
+size_t packed16_bytes(int N, int K) { return (size_t)((N + 15) / 16 * 16) * K * 2; }
+
+int launch_pack_weight16(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out) {
+    if (K % 32) return rt_fail(ctx, RT_ERR_INVALID, "pack16: K=%d must be a multiple of 32", K);
+    const int Np = (N + 15) / 16 * 16;
+    const int64_t pieces = (int64_t)(Np / 16) * (K / 32) * 64;
+    int64_t blocks = (pieces + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pack_weight16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_src, N, K, Np, d_dst);
+    RT_HIP(ctx, hipGetLastError());
+    out->data16 = d_dst;
+    out->Np16 = Np;
+    return RT_OK;
 }
 
 int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out) {

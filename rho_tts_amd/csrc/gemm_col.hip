@@ -1,4 +1,4 @@
-// Column-owner decode GEMM for gfx950 (M <= 64 rows): one workgroup owns a 32-column tile of the output for the
+// Column-owner decode GEMM for gfx950 (M <= 32 rows per launch): one workgroup owns a 16-column tile of the output for the
 // WHOLE K, its 8 waves split K, every wave streams its own contiguous run of pre-tiled weights from HBM with
 // non-temporal 1-KiB loads (each weight byte is read exactly once, by exactly one wave), partial accumulators are
 // combined through LDS in a fixed order (deterministic, no float atomics, no partial slabs in HBM), and because a
@@ -10,7 +10,7 @@
 //                     NEW x are emitted for the next GEMM's NORM prologue
 //             SILU  : the workgroup owns gate tile j and up tile j: act = silu(gate) * up -> bf16
 // This takes a decoder layer at decode time from 9 launches to 5 (qkv, attention, o, gate/up, down).
-// HBM-bound: N*K*2 bytes per launch; MFMA v_mfma_f32_32x32x16_bf16 at a few % utilisation keeps it that way.
+// HBM-bound: N*K*2 bytes per launch; MFMA v_mfma_f32_16x16x32_bf16 at a few % utilisation keeps it that way.
 #include <hip/hip_ext.h>
 
 #include "kernels.h"
@@ -30,18 +30,27 @@ __device__ __forceinline__ unsigned pk2(float lo, float hi) { return f32x2_to_bf
 
 constexpr int WAVES = 8;    // 512 threads, 2 waves per SIMD: 256 VGPRs per wave for deep load queues
 
+typedef __attribute__((ext_vector_type(4))) float f4acc_t;
+__device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+}
+
+// 16-column tiles (v_mfma_f32_16x16x32_bf16): twice the workgroups of a 32-column tiling, and a CU cannot pull more
+// than ~24 GB/s out of HBM on its own, so the narrow GEMMs of a decode step (N = hidden) only reach the chip's
+// bandwidth when they are spread over that many CUs.
+//
 // RMSNorm without touching the operand twice: y = rmsnorm(x) W^T = inv_row * ((w .* x) W^T).  The producer of x (the
 // RESID epilogue, or k_rowsq for the first GEMM of a stack) already stored bf16(w_next .* x) in fragment-tiled order, so
 // every GEMM reads a plain bf16 operand with one coalesced load per tile, and the row scale inv_row - from the
 // producer's per-tile sums of squares - is applied to the accumulator in the epilogue (post_scale).
 template <int EPI>
 __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
-    __shared__ float red[WAVES][16][64];   // 32 KiB: one accumulator tile per wave
-    __shared__ float sh_inv[32];           // RMSNorm row scales
+    __shared__ float red[WAVES][2][4][64];   // 16 KiB: two 16x16 accumulator tiles (rows 0-15, 16-31) per wave
+    __shared__ float sh_inv[32];             // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int C = (NB == 2) ? 4 : 8;   // k-tiles per super-chunk
+    constexpr int C = (NB == 2) ? 4 : 8;     // k-tiles (32 deep) per super-chunk
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int r = lane & 15, qd = lane >> 4;
     const int nt = blockIdx.x;
     const int kchunk = (g.KT + WAVES - 1) / WAVES;
     const int kt_lo = w * kchunk;
@@ -53,13 +62,19 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     const s8_t* wp[NB];
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
-    const int arow = g.row_off + (r < g.M ? r : g.M - 1);          // clamp: computed on valid memory, never stored
-    // fragment-tiled A: this lane's 8 elements of k-tile kt sit at tile_off(arow, 16 kt + 8 h); consecutive lanes are contiguous
-    const s8_t* ap = reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.A) + tile_off(arow, kt_lo * 16 + h * 8, g.KT));
+    // fragment-tiled A, two 16-row sub-blocks: this lane's 8 elements of k-tile kt sit at tile_off(row, 32 kt + 8 qd)
+    const s8_t* ap[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int row = mt * 16 + r;
+        if (row >= g.M) row = g.M - 1;                  // clamp: computed on valid memory, never stored
+        ap[mt] = reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.A) + tile_off(g.row_off + row, kt_lo * 32 + qd * 8, g.K));
+    }
+    const bool two = g.M > 16;                          // second sub-block present
 
     struct Chunk {
         s8_t b[NB][C];
-        s8_t a[C];
+        s8_t a[2][C];
     };
     auto issue = [&](int sc, Chunk& ck) {
 #pragma unroll
@@ -68,51 +83,48 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
 #pragma unroll
             for (int b = 0; b < NB; ++b) ck.b[b][u] = g.nt ? __builtin_nontemporal_load(wp[b] + (int64_t)k * 64) : wp[b][(int64_t)k * 64];
-            ck.a[u] = ap[(int64_t)k * 64];            // 64 lanes x 16 B = the next contiguous KiB
+            ck.a[0][u] = ap[0][(int64_t)k * 64];      // 64 lanes x 16 B = the next contiguous KiB of the sub-block
+            ck.a[1][u] = ap[1][(int64_t)k * 64];
         }
     };
 
     Chunk c0, c1;
     if (n_sc > 0) issue(0, c0);
-    // residual values this thread will update in the epilogue (elements tid and tid + 512 of the 32x32 tile)
-    const int n = nt * 32 + (tid & 31);
-    const int e_h = (tid >> 5) & 1;
-    float xres[2] = {0.f, 0.f};
-    if (EPI == COL_RESID) {
+    // the output element this thread finishes in the epilogue: sub-block mt, accumulator register i, lane l
+    const int e_mt = tid >> 8, e_i = (tid >> 6) & 3, e_l = tid & 63;
+    const int e_row = e_mt * 16 + (e_l >> 4) * 4 + e_i;
+    const int n = nt * 16 + (e_l & 15);
+    float xres = 0.f;
+    if (EPI == COL_RESID && e_row < g.M && n < g.N) xres = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
+    if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns row 4w + qd, its lanes split the partials
+        const int row_i = 4 * w + qd;
+        const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
+        const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
+        float s = 0.f;
+        for (int j = r; j < g.rowsq_n; j += 16) s += p[j];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = (tid + q * 512) >> 6;
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
-            if (row < g.M && n < g.N) xres[q] = g.out[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))];
-        }
-    }
-    if (g.post_scale) {   // row scales: half-wave (w, h) owns rows 2w + h and 2w + h + 16, its 32 lanes split the partials
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row_i = 2 * w + h + 16 * rr;
-            const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
-            const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
-            float s = 0.f;
-            for (int j = r; j < g.rowsq_n; j += 32) s += p[j];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
-        }
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
     }
     if (n_sc > 1) issue(1, c1);
 
-    f16_t acc[NB];
+    f4acc_t acc[NB][2];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[b][mt][i] = 0.f;
 
     auto consume = [&](int sc, Chunk& ck) {
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             if (sc * C + u < n_k) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b] = mfma32(ck.a[u], ck.b[b][u], acc[b]);
+                for (int b = 0; b < NB; ++b) {
+                    acc[b][0] = mfma16(ck.a[0][u], ck.b[b][u], acc[b][0]);
+                    if (two) acc[b][1] = mfma16(ck.a[1][u], ck.b[b][u], acc[b][1]);
+                }
             }
         }
     };
@@ -125,54 +137,48 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         }
     }
 
-    // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue
-    float val[NB][2];
+    // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue (one output per thread)
+    float val[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (b > 0) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[b][i];
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[w][mt][i][lane] = acc[b][mt][i];
         __syncthreads();
+        float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * 512;
-            const int i = e >> 6, l = e & 63;
-            float s = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < WAVES; ++ww) s += red[ww][i][l];
-            val[b][q] = s;
-        }
+        for (int ww = 0; ww < WAVES; ++ww) s += red[ww][e_mt][e_i][e_l];
+        val[b] = s;
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = (tid + q * 512) >> 6;
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * e_h;
-        const bool ok = row < g.M && n < g.N;
-        const float inv = g.post_scale ? sh_inv[row & 31] : 1.f;     // (sh_inv was published before the reduce barriers)
-        float v = val[0][q] * inv;
+    {
+        const bool ok = e_row < g.M && n < g.N;
+        const float inv = g.post_scale ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
+        float v = val[0] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
                 if (g.bias) v += g.bias[n];
-                g.out[(int64_t)(g.row_off + row) * g.ldc + n] = v;      // STORE outputs (qkv, logits, mtp rows) stay row-major
+                g.out[(int64_t)(g.row_off + e_row) * g.ldc + n] = v;    // STORE outputs (qkv, logits, mtp rows) stay row-major
             }
         } else if (EPI == COL_RESID) {
             float xn = 0.f;
             if (ok) {
                 if (g.bias) v += g.bias[n];
                 if (g.scale) v *= g.scale[n];
-                xn = xres[q] + v;
-                const int64_t o = tile_off(g.row_off + row, n, (int)(g.ldc >> 4));
+                xn = xres + v;
+                const int64_t o = tile_off(g.row_off + e_row, n, (int)g.ldc);
                 g.out[o] = xn;
                 if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(g.next_norm_w[n] * xn);   // operand of the GEMM behind the next RMSNorm
             }
-            float sq = xn * xn;                   // half-wave = one row's 32 columns
+            float sq = xn * xn;                   // a 16-lane group = one row's 16 columns
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            if ((tid & 31) == 0 && row < g.M) g.rowsq_out[(int64_t)(g.row_off + row) * g.rowsq_out_n + nt] = sq;
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + nt] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
-                const float u = val[NB - 1][q] * inv;
-                g.out_bf16[tile_off(g.row_off + row, n, (int)(g.ldc >> 4))] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
+                const float u = val[NB - 1] * inv;
+                g.out_bf16[tile_off(g.row_off + e_row, n, (int)g.ldc)] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
             }
         }
     }
@@ -202,14 +208,15 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.M < 1 || a.M > 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..32 (callers split larger row blocks)", a.M);
-    if (w.K != w.Kp || w.K != a.K) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: K mismatch (%d vs %d) or not a multiple of 16", w.K, a.K);
+    if (w.K != a.K || w.K % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: K mismatch (%d vs %d) or not a multiple of 32", w.K, a.K);
+    if (!w.data16) return rt_fail(ctx, RT_ERR_STATE, "gemm_col: weight has no 16-column decode copy");
     ColArgs g = a;
-    g.Wp = w.data;
-    g.NT = w.Np / 32;
-    g.KT = w.Kp / 16;
+    g.Wp = w.data16;
+    g.NT = w.Np16 / 16;
+    g.KT = w.K / 32;
     int tiles = g.NT;
     if (g.epi == COL_SILU) {
-        if (w.N % 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: gate/up width %d not a multiple of 64", w.N);
+        if (w.N % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: gate/up width %d not a multiple of 32", w.N);
         tiles = g.NT / 2;
         g.up_tile_offset = g.NT / 2;
         g.N = w.N / 2;

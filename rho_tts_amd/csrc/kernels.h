@@ -12,6 +12,10 @@ struct PackedW {
     int N = 0, K = 0;              // logical
     int Np = 0, Kp = 0;            // padded to 32 / 16 (zero filled)
     size_t bytes() const { return (size_t)Np * Kp * 2; }
+    // second copy for the decode path, tiled for v_mfma_f32_16x16x32_bf16: tile (n/16, k/32) = 64 lanes x 16 B,
+    // lane (q<<4 | c) holding W[16 nt + c][32 kt + 8 q .. +8]   (K % 32 == 0; N padded to 16)
+    const bf16_t* data16 = nullptr;
+    int Np16 = 0;
 };
 
 // Implicit-GEMM view of the A operand: row m = (b, t) of an activation tensor [B][T_in][Cin]
@@ -55,6 +59,8 @@ struct GemmEpi {
 size_t packed_bytes(int N, int K);
 // d_dst must hold packed_bytes(N, K); d_src is row-major bf16 [N][K] in HBM.
 int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
+size_t packed16_bytes(int N, int K);
+int launch_pack_weight16(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
 int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e);
 // Weight-streaming form for M <= 64 rows (decode): plain bf16 A [M][K], raw f32 slabs out.
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,

@@ -21,6 +21,7 @@ struct Slot {
     bf16_t* tbl = nullptr;
     float* vec = nullptr;
     void* raw = nullptr;  // owning pointer
+    void* raw16 = nullptr;  // owning pointer of the 16-column decode copy
 };
 
 struct LayerW {
@@ -395,7 +396,7 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
                  int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
-    const int H = d.hidden, NTh = H / 32, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
+    const int H = d.hidden, NTh = H / 16, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
     const bool isp = &S == &m->pred;
     for (int i = 0; i < d.layers; ++i) {
         LayerW& L = S.L[i];
@@ -504,7 +505,7 @@ int rt_model_destroy(rt_model* m) {
     std::lock_guard<std::mutex> g(ctx->mu);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& s : m->slots) if (s.raw) (void)hipFree(s.raw);
+    for (auto& s : m->slots) { if (s.raw) (void)hipFree(s.raw); if (s.raw16) (void)hipFree(s.raw16); }
     for (StackW* S : {&m->talker, &m->pred, &m->ctf}) {
         if (S->kv.k) (void)hipFree(S->kv.k);
         if (S->kv.v) (void)hipFree(S->kv.v);
@@ -561,6 +562,15 @@ int rt_model_set_tensor(rt_model* m, const char* name, const void* data, int32_t
         RT_HIP(ctx, hipMalloc(&s->raw, pb));
         RT_TRY(launch_pack_weight(ctx, (const bf16_t*)d_src, (int)rows, (int)cols, (bf16_t*)s->raw, &s->pw));
         m->weight_bytes += (int64_t)pb;
+        // weights the decode step streams get a second copy tiled for the 16-column GEMM (talker / predictor layers, heads, mtp)
+        const std::string nm(name);
+        const bool decode_w = nm.rfind("talker.l", 0) == 0 || nm.rfind("pred.l", 0) == 0 || nm.rfind("pred.head", 0) == 0 ||
+                              nm == "pred.mtp" || nm == "talker.codec_head";
+        if (decode_w && cols % 32 == 0) {
+            if (s->raw16) { RT_HIP(ctx, hipFree(s->raw16)); s->raw16 = nullptr; }
+            RT_HIP(ctx, hipMalloc(&s->raw16, packed16_bytes((int)rows, (int)cols)));
+            RT_TRY(launch_pack_weight16(ctx, (const bf16_t*)d_src, (int)rows, (int)cols, (bf16_t*)s->raw16, &s->pw));
+        }
     } else if (s->kind == K_TABLE) {
         RT_HIP(ctx, hipMalloc(&s->raw, (size_t)n * 2));
         RT_HIP(ctx, hipMemcpyAsync(s->raw, d_src, (size_t)n * 2, hipMemcpyDeviceToDevice, ctx->stream));
@@ -877,8 +887,9 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_HIP(ctx, hipMemcpyAsync(d_forced, forced_host.data(), forced_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     // decode state.  Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
-    const bool col = g_decode_col && B2 <= 64 && m->has_mtp();   // (equal-width predictor: the legacy path materialises the past hidden)
-    const int NTt = H / 32, NTp = Hp / 32;
+    const bool col = g_decode_col && B2 <= 64 && m->has_mtp() && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 &&
+                     c.predictor.inter % 32 == 0;   // (equal-width predictor: the legacy path materialises the past hidden)
+    const int NTt = H / 16, NTp = Hp / 16;
     float *rowsq_t = nullptr, *rowsq_p = nullptr, *x_all = x;
     DecWs dwt, dwp;
     StackWs wt, wp;

@@ -81,13 +81,13 @@ __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int 
     for (int i = threadIdx.x; i < (H >> 2); i += 256) {
         const f4_t v = xr[i];
         ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        if (x_tiled) *reinterpret_cast<f4_t*>(x_tiled + tile_off((int)row, i * 4, H >> 4)) = v;
+        if (x_tiled) *reinterpret_cast<f4_t*>(x_tiled + tile_off((int)row, i * 4, H)) = v;
         if (a_tiled) {   // bf16(norm_w .* x): the first GEMM's operand (its row scale is applied after the product)
             const f4_t wv = reinterpret_cast<const f4_t*>(norm_w)[i];
             uint2 pk;
             pk.x = f32x2_to_bf16x2(wv[0] * v[0], wv[1] * v[1]);
             pk.y = f32x2_to_bf16x2(wv[2] * v[2], wv[3] * v[3]);
-            *reinterpret_cast<uint2*>(a_tiled + tile_off((int)row, i * 4, H >> 4)) = pk;
+            *reinterpret_cast<uint2*>(a_tiled + tile_off((int)row, i * 4, H)) = pk;
         }
     }
     const float tot = block_sum_f32(ss, sh);
