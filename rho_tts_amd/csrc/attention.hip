@@ -13,8 +13,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 // FUSED (decode rows only, one row per sequence slot): `q` is the raw qkv projection [M][(heads+2kv)*D]; the workgroup
 // first finishes its own head group - RMSNorm over the head, rotate-half RoPE, K/V rounded to bf16 and appended to
 // the cache row (slot, pos) - then attends over the cache including the row it has just written.
-template <int D, int REP, bool FUSED>
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, int heads, int kv_heads,
+template <int D, int REP, bool FUSED, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__ q, int heads, int kv_heads,
                                                    const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
                                                    int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                    int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
-    __shared__ float sh[4][REP][LPP][10];
+    __shared__ float sh[NW][REP][LPP][10];     // NW waves split the cached positions of one (row, kv head)
     __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
 
     // x = kv head (fastest): workgroups are dealt round-robin over the 8 XCDs, so with 8 kv heads every XCD's L2 holds
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
         // vectors of this head group: REP query heads, then K, then V; wave w takes vectors w, w+4, ...
         constexpr int half = D / 2;
         const int width = (heads + 2 * kv_heads) * D;
-        for (int vec = w; vec < REP + 2; vec += 4) {
+        for (int vec = w; vec < REP + 2; vec += NW) {
             const bool is_q = vec < REP, is_k = vec == REP;
             const int col0 = is_q ? (kh * REP + vec) * D : (is_k ? (heads + kh) * D : (heads + kv_heads + kh) * D);
             const bool act = lane < half;
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
     // rows below prefix_len come from the shared prefix slot (same bytes for every sequence -> cache hits)
     const int64_t pdelta = prefix_slot >= 0 ? (((int64_t)prefix_slot - slot) * kv_heads * max_pos) * D : 0;
 
-    for (int p0 = lo + w * PPW + pg; p0 <= hi; p0 += 4 * PPW * U) {
+    for (int p0 = lo + w * PPW + pg; p0 <= hi; p0 += NW * PPW * U) {
         u4_t kk[U], vv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * 4 * PPW;
+            const int p = p0 + u * NW * PPW;
             const int pc = p <= hi ? p : hi;
             const int64_t po = (int64_t)pc * D + (pc < prefix_len ? pdelta : 0);
             kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * 4 * PPW;
+            const int p = p0 + u * NW * PPW;
             float kf[8], vf[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -156,15 +156,15 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
         }
     }
     __syncthreads();
-    // final merge over the 4 waves: thread t -> (r, sub, j)
-    for (int t = threadIdx.x; t < REP * LPP * 8; t += 256) {
+    // final merge over the NW waves: thread t -> (r, sub, j)
+    for (int t = threadIdx.x; t < REP * LPP * 8; t += NW * 64) {
         const int j = t & 7, sb = (t >> 3) % LPP, r = t / (8 * LPP);
         float mn = -1e30f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) mn = fmaxf(mn, sh[ww][r][sb][0]);
+        for (int ww = 0; ww < NW; ++ww) mn = fmaxf(mn, sh[ww][r][sb][0]);
         float lt = 0.f, at = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
+        for (int ww = 0; ww < NW; ++ww) {
             const float c = __expf(sh[ww][r][sb][0] - mn);
             lt += sh[ww][r][sb][1] * c;
             at += sh[ww][r][sb][2 + j] * c;
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ q, 
 
 struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len; };
 
-template <int D, bool FUSED>
+template <int D, bool FUSED, int NW>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED>), grid, dim3(256), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -202,12 +202,19 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
     bf16_t* kc = kv.k + layer * kv.layer_stride();
     bf16_t* vc = kv.v + layer * kv.layer_stride();
     dim3 grid(kv_heads, M);
+    // few rows with long contexts (the talker's decode step over a long KV row): 16 waves split the positions;
+    // many rows or short contexts (prefill, predictor, sliding window): 4 waves are plenty
+    const bool wide = M * kv_heads <= 512 && kv.max_pos > 64 && (window <= 0 || window > 256);
+#define RT_ATT(DD)                                                                                                                   \
+    return wide ? dispatch_rep<DD, FUSED, 16>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f) \
+                : dispatch_rep<DD, FUSED, 4>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f)
     switch (head_dim) {
-        case 32: return dispatch_rep<32, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
-        case 64: return dispatch_rep<64, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
-        case 128: return dispatch_rep<128, FUSED>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+        case 32: RT_ATT(32);
+        case 64: RT_ATT(64);
+        case 128: RT_ATT(128);
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32, 64, 128)", head_dim);
     }
+#undef RT_ATT
 }
 
 }  // namespace
