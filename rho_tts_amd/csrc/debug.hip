@@ -85,7 +85,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
     a.do_sample = sp->do_sample; a.temperature = sp->temperature; a.top_k = sp->top_k; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
     a.seen = d_seen; a.suppress_from = suppress_from; a.allow_token = allow_token; a.seed = seed; a.item_ids = items; a.frame = frame; a.group = group;
     a.forced = nullptr; a.out = d_out; a.out_stride = 1; a.eos_token = -1; a.eos_flag = nullptr; a.logits_copy = nullptr;
-    a.frame_ptr = nullptr; a.seed_ptr = nullptr;
+    a.frame_ptr = nullptr; a.seed_ptr = nullptr; a.stamps = nullptr;
     int rc = launch_sample(ctx, a);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(items);
@@ -223,6 +223,43 @@ int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use_graph,
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(buf);
     return RT_OK;
+}
+
+// Sampler microbenchmark: `iters` back-to-back launches over M rows of V logits; returns the average launch time and
+// (row 0 of the last launch) the 100-MHz wall-clock stamps at the kernel's phase boundaries.
+int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, int32_t iters, double* avg_us,
+                    int64_t* stamps8) {
+    if (!ctx || !d_logits || !sp || !avg_us || M < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_sample: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t* items = nullptr;
+    int32_t* out = nullptr;
+    long long* st = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&items, (size_t)M * 8));
+    RT_HIP(ctx, hipMalloc((void**)&out, (size_t)M * 4));
+    RT_HIP(ctx, hipMalloc((void**)&st, 8 * 8));
+    RT_HIP(ctx, hipMemsetAsync(st, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_iota64, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, items, M);
+    SampleArgs a{};
+    a.logits = d_logits; a.n_slabs = 1; a.M = M; a.V = V;
+    a.do_sample = sp->do_sample; a.temperature = sp->temperature; a.top_k = sp->top_k; a.top_p = sp->top_p; a.rep_penalty = sp->repetition_penalty;
+    a.suppress_from = V; a.allow_token = -1; a.seed = 1; a.item_ids = items; a.out = out; a.out_stride = 1; a.eos_token = -1;
+    a.stamps = st;
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    int rc = launch_sample(ctx, a);
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters && rc == RT_OK; ++i) { a.frame = i; rc = launch_sample(ctx, a); }
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / iters;
+    if (stamps8) RT_HIP(ctx, hipMemcpy(stamps8, st, 64, hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(items); (void)hipFree(out); (void)hipFree(st);
+    return rc;
 }
 
 }  // extern "C"

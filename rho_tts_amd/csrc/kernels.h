@@ -184,6 +184,7 @@ struct SampleArgs {
     const int32_t* frame_ptr;
     int64_t out_fs, eos_fs, forced_fs, copy_fs;
     int eos_live, min_frames;
+    long long* stamps;         // debug: wall-clock (100 MHz) stamps of row 0 at the phase boundaries, or null
 };
 int launch_sample(rt_ctx* ctx, const SampleArgs& a);
 

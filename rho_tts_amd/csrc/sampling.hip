@@ -203,6 +203,258 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-native sampler (V <= 4096): every value lives in a register, the k-th largest is found by a bit-serial radix
+// select made of 64-lane ballots (no LDS histograms, no atomics), each of the 4 waves keeps its own top-k, wave 0
+// selects the final k out of those 4k with unique 64-bit (value, index) keys, sorts them with the one-wave bitonic
+// network and walks the ordered CDF exactly as oracle/sampling.py defines it.
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// k-th largest of the wave's NQ x 64 keys: bit-serial search for the largest pivot with count(key >= pivot) >= k.  Per
+// (register, bit) the vector unit does ONE compare against a scalar pivot; counting and the decision are SALU.  Stops as
+// soon as a pivot separates exactly k keys (`exact`: the top k are key >= result); after all 32 bits the result is the
+// k-th largest key itself and equal keys may straddle the cut.  Needs 1 <= k <= number of non-zero keys.
+template <int NQ>
+__device__ __forceinline__ unsigned wave_kth_key(const unsigned (&key)[NQ], int k, bool& exact) {
+    unsigned prefix = 0;
+    exact = false;
+    for (unsigned bm = 0x80000000u; bm != 0u; bm >>= 1) {
+        const unsigned pivot = prefix | bm;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) cnt += __popcll(__ballot(key[j] >= pivot));
+        if (cnt >= k) {
+            prefix = pivot;
+            if (cnt == k) { exact = true; break; }
+        }
+    }
+    return prefix;
+}
+__device__ __forceinline__ float lane_f32(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
+__device__ __forceinline__ int lane_i32(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
+    __shared__ Cand wc[4][64];
+    __shared__ int wcount[4];
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, V = A.V;
+    const int64_t slab_stride = (int64_t)A.M * V;
+    if (A.seed_ptr) A.seed = *A.seed_ptr;
+    if (A.frame_ptr) {     // graph replay: frame index and frame-strided buffers resolved on the device
+        const int f = *A.frame_ptr;
+        A.frame = f;
+        A.out += (int64_t)f * A.out_fs;
+        if (A.eos_flag) A.eos_flag += (int64_t)f * A.eos_fs;
+        if (A.forced) A.forced += (int64_t)f * A.forced_fs;
+        if (A.logits_copy) A.logits_copy += (int64_t)f * A.copy_fs;
+        A.allow_token = (A.eos_live && f >= A.min_frames) ? A.eos_token : -1;
+    }
+    uint8_t* seen = A.seen ? A.seen + (int64_t)row * V : nullptr;
+
+    // element j of this thread has index w*64*NV... no: idx = (w * NV + j) * 64 + lane, so that inside a wave the index
+    // grows with (j, lane): ties at the selection threshold are then resolved by position = by lowest index
+    if (A.stamps && row == 0 && tid == 0) A.stamps[0] = wall_clock64();
+    float v[NV];
+    unsigned key[NV];
+    bool valid[NV];
+    // all loads first (independent, in flight together): a load placed after the logits_copy store of the previous
+    // element would have to wait for it (possible aliasing) and the loop degenerates into NV serial round trips
+    const float* __restrict__ lg = A.logits + (int64_t)row * V;
+    const uint8_t* __restrict__ seen_r = seen;
+    uint8_t sn[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (w * NV + j) * 64 + lane;
+        valid[j] = i < V;
+        v[j] = valid[j] ? 0.f + lg[i] : 0.f;
+        sn[j] = (seen_r && valid[j]) ? seen_r[i] : (uint8_t)0;
+    }
+    for (int sb = 1; sb < A.n_slabs; ++sb) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (w * NV + j) * 64 + lane;
+            if (valid[j]) v[j] += lg[sb * slab_stride + i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (w * NV + j) * 64 + lane;
+        float l = -INFINITY;
+        if (valid[j]) {
+            l = v[j];
+            if (A.logits_copy) A.logits_copy[(int64_t)row * V + i] = l;
+            if (A.rep_penalty != 1.0f && sn[j]) l = l > 0.f ? __fdiv_rn(l, A.rep_penalty) : __fmul_rn(l, A.rep_penalty);
+            if (i >= A.suppress_from && i != A.allow_token) l = -INFINITY;
+            if (A.do_sample) l = __fdiv_rn(l, A.temperature);
+        }
+        v[j] = l;
+        key[j] = okey(l);
+    }
+
+    if (A.stamps && row == 0 && tid == 0) A.stamps[1] = wall_clock64();
+    int token = -1;
+    const int forced = A.forced ? A.forced[row] : -1;
+    bool need_argmax = !A.do_sample;
+    if (forced >= 0) {
+        token = forced;
+        need_argmax = false;
+    } else if (A.do_sample) {
+        if (A.stamps && row == 0 && tid == 0) A.stamps[2] = wall_clock64();
+        const int k = A.top_k < V ? A.top_k : V;
+        // ---- phase 1: this wave's own top-k (equal keys at the cut: lowest positions = lowest indices first)
+        int n_valid = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { n_valid += __popcll(__ballot(valid[j])); if (!valid[j]) key[j] = 0u; }
+        const int kw = k < n_valid ? k : n_valid;
+        bool exact = false;
+        const unsigned thr = kw > 0 ? wave_kth_key<NV>(key, kw, exact) : 0xFFFFFFFFu;
+        int need = 0;
+        if (kw > 0 && !exact) {
+            int n_gt = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) n_gt += __popcll(__ballot(key[j] > thr));
+            need = kw - n_gt;
+        }
+        int base = 0, tie_seen = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            bool sel;
+            if (exact) {
+                sel = key[j] >= thr;
+            } else {
+                const bool eq = kw > 0 && key[j] == thr;
+                const unsigned long long b_eq = __ballot(eq);
+                sel = (kw > 0 && key[j] > thr) || (eq && tie_seen + lanes_below(b_eq) < need);
+                tie_seen += __popcll(b_eq);
+            }
+            sel = sel && valid[j];
+            const unsigned long long b_sel = __ballot(sel);
+            if (sel) {
+                const int pos = base + lanes_below(b_sel);
+                if (pos < 64) { wc[w][pos].v = v[j]; wc[w][pos].idx = (w * NV + j) * 64 + lane; }
+            }
+            base += __popcll(b_sel);
+        }
+        if (A.stamps && row == 0 && tid == 0) A.stamps[3] = wall_clock64();
+        if (lane == 0) wcount[w] = base < 64 ? base : 64;
+        __syncthreads();
+        // ---- phase 2 (wave 0): the final k out of the 4 lists
+        if (w == 0) {
+            __shared__ Cand fin[64];
+            __shared__ Cand sorted[64];
+            Cand c4[4];
+            unsigned k32[4];
+            int total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nq = __builtin_amdgcn_readfirstlane(wcount[q]);
+                const bool ok = lane < nq;
+                c4[q] = ok ? wc[q][lane] : Cand{-INFINITY, 0x7fffffff};
+                k32[q] = ok ? okey(c4[q].v) : 0u;
+                total += nq;
+            }
+            const int kf = k < total ? k : total;
+            bool ex2 = false;
+            const unsigned thr2 = kf > 0 ? wave_kth_key<4>(k32, kf, ex2) : 0xFFFFFFFFu;
+            // values equal to the k-th one go to the lowest indices: a second search over the (unique) inverted indices
+            unsigned inv[4];
+            unsigned thr3 = 0u;
+            if (kf > 0 && !ex2) {
+                int n_gt = 0, n_eq = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    n_gt += __popcll(__ballot(k32[q] > thr2));
+                    n_eq += __popcll(__ballot(k32[q] == thr2));
+                    inv[q] = k32[q] == thr2 ? 0xFFFFFFFFu - (unsigned)c4[q].idx : 0u;
+                }
+                if (n_eq > kf - n_gt) { bool ex3; thr3 = wave_kth_key<4>(inv, kf - n_gt, ex3); }
+            }
+            fin[lane] = Cand{-INFINITY, 0x7fffffff};
+            int b2 = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool sel = kf > 0 && k32[q] != 0u && (ex2 ? k32[q] >= thr2 : (k32[q] > thr2 || (k32[q] == thr2 && inv[q] >= thr3)));
+                const unsigned long long bs = __ballot(sel);
+                if (sel) { const int pos = b2 + lanes_below(bs); if (pos < 64) fin[pos] = c4[q]; }
+                b2 += __popcll(bs);
+            }
+            if (A.stamps && row == 0 && tid == 0) A.stamps[4] = wall_clock64();
+            // ---- order by (value desc, index asc): rank = number of candidates ahead of mine (keys are unique), one
+            // scalar broadcast per candidate, then a scatter through LDS puts candidate r on lane r
+            Cand c = fin[lane];
+            const unsigned my_hi = okey(c.v), my_lo = 0xFFFFFFFFu - (unsigned)c.idx;     // larger 64-bit key = earlier
+            const unsigned long long my64 = ((unsigned long long)my_hi << 32) | my_lo;
+            int rank = 0;
+#pragma unroll 4
+            for (int j = 0; j < kf; ++j) {
+                const unsigned long long o64 = ((unsigned long long)(unsigned)lane_i32((int)my_hi, j) << 32) | (unsigned)lane_i32((int)my_lo, j);
+                rank += o64 > my64 ? 1 : 0;
+            }
+            if (lane < kf) sorted[rank] = c;
+            c = lane < kf ? sorted[lane] : Cand{-INFINITY, 0x7fffffff};
+            if (A.stamps && row == 0 && tid == 0) A.stamps[5] = wall_clock64();
+            const unsigned long long fin_mask = __ballot(lane < kf && c.v > -INFINITY);
+            const int n = __popcll(fin_mask);                                  // finite candidates are a prefix after the sort
+            if (n > 0) {
+                const float mx = lane_f32(c.v, 0);
+                const float p = lane < n ? expf(__fsub_rn(c.v, mx)) : 0.f;
+                float tot = 0.f;
+                for (int j = 0; j < n; ++j) tot = __fadd_rn(tot, lane_f32(p, j));
+                int keep = n;
+                if (A.top_p < 1.0f) {
+                    const float lim = __fmul_rn(A.top_p, tot);
+                    float cum = 0.f;
+                    for (int j = 0; j < n; ++j) { cum = __fadd_rn(cum, lane_f32(p, j)); if (cum >= lim) { keep = j + 1; break; } }
+                    tot = cum;
+                }
+                const float u = rt_uniform(A.seed, (unsigned)A.item_ids[row], (unsigned)A.frame, (unsigned)A.group);
+                const float target = __fmul_rn(u, tot);
+                float cum = 0.f;
+                int pick_lane = keep - 1;
+                for (int j = 0; j < keep; ++j) { cum = __fadd_rn(cum, lane_f32(p, j)); if (cum > target) { pick_lane = j; break; } }
+                token = lane_i32(c.idx, pick_lane);
+            }
+            if (lane == 0) sh_i[0] = n > 0 ? 0 : 1;      // no finite candidate at all: fall back to the arg-max rule
+        }
+        __syncthreads();
+        need_argmax = sh_i[0] != 0;
+        __syncthreads();
+    }
+    if (need_argmax) {
+        // ---- arg-max, lowest index on ties (greedy result, and the fallback when no candidate is finite)
+        float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = (w * NV + j) * 64 + lane;
+            if (valid[j] && (v[j] > bv || (v[j] == bv && i < bi))) { bv = v[j]; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sh_f[w] = bv; sh_i[w] = bi; }
+        __syncthreads();
+        bv = sh_f[0]; bi = sh_i[0];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) if (sh_f[ww] > bv || (sh_f[ww] == bv && sh_i[ww] < bi)) { bv = sh_f[ww]; bi = sh_i[ww]; }
+        if (bi == 0x7fffffff) bi = 0;
+        token = bi;
+    }
+    if (A.stamps && row == 0 && tid == 0) A.stamps[6] = wall_clock64();
+    if (tid == 0) {
+        if (seen && token >= 0 && token < V) seen[token] = 1;
+        int is_eos = 0;
+        if (A.eos_token >= 0 && token == A.eos_token) { is_eos = 1; token = 0; }
+        if (A.eos_flag) A.eos_flag[row] = is_eos;
+        A.out[(int64_t)row * A.out_stride] = token;
+    }
+}
+
 }  // namespace
 
 int launch_sample(rt_ctx* ctx, const SampleArgs& a) {
@@ -210,7 +462,10 @@ int launch_sample(rt_ctx* ctx, const SampleArgs& a) {
     if (a.do_sample && (a.top_k < 1 || a.top_k > 64)) return rt_fail(ctx, RT_ERR_INVALID, "sampling needs 1 <= top_k <= 64 (got %d)", a.top_k);
     if (a.do_sample && !(a.temperature > 0.f)) return rt_fail(ctx, RT_ERR_INVALID, "sampling needs temperature > 0");
     if (a.V > 16384) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "vocabulary %d too large for the sampler", a.V);
-    hipLaunchKernelGGL(k_sample, dim3(a.M), dim3(256), a.V * sizeof(float), ctx->stream, a);
+    if (a.V <= 1024) hipLaunchKernelGGL(k_sample_w<4>, dim3(a.M), dim3(256), 0, ctx->stream, a);
+    else if (a.V <= 2048) hipLaunchKernelGGL(k_sample_w<8>, dim3(a.M), dim3(256), 0, ctx->stream, a);
+    else if (a.V <= 4096) hipLaunchKernelGGL(k_sample_w<16>, dim3(a.M), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_sample, dim3(a.M), dim3(256), a.V * sizeof(float), ctx->stream, a);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
