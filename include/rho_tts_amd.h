@@ -267,8 +267,9 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  * cycles over n_mats weight matrices (choose n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);
 RT_API int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_norm, int32_t epi, int32_t n_mats, int32_t iters,
-                             double* avg_us);
+                             double* avg_us, int64_t* stamps8);
 RT_API int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use_graph, int32_t reps, double* us_per_launch);
+RT_API int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, int32_t mode, double* us_per_barrier, int32_t* aborted);
 RT_API int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, int32_t iters, double* avg_us,
                            int64_t* stamps8);
 RT_API int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t split_k, int32_t n_mats, int32_t iters,

@@ -95,3 +95,41 @@ __device__ __forceinline__ unsigned f32x2_to_bf16x2(float lo, float hi) {
     const rt_bf2_t v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
 }
+
+// Grid-wide barrier for a persistent kernel whose workgroups are ALL co-resident (grid <= CUs x occupancy, checked on
+// the host).  bar[0] is a monotonic arrival counter, bar[1] an abort flag; both zeroed by the host before the launch.
+// Every workgroup calls it with the same epoch 1, 2, 3 ...  The wait is bounded: after `max_spins` polls (or when
+// another workgroup has given up) the barrier raises the abort flag and returns false, and the caller must return - a
+// launch that is not fully resident therefore ends with an error instead of hanging the GPU.
+// MODE 0: bulk cache maintenance (release write-back by thread 0, acquire invalidate by every wave) - any plain store
+//         before the barrier is visible to any plain load after it, at the price of L2-wide flushes per workgroup;
+// MODE 2: no cache maintenance - only data moved with agent-scope accesses (st_agent / ld_agent below: write-through
+//         stores, L2-bypassing loads) is exchanged, which costs nothing at the barrier itself.
+template <int MODE = 0>
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned n_wg, unsigned epoch, unsigned max_spins = 1u << 22) {
+    __shared__ int gb_ok;
+    if (MODE == 2) __builtin_amdgcn_s_waitcnt(0);           // this wave's write-through stores have been acknowledged
+    __syncthreads();                                        // every wave's stores are issued and complete at workgroup scope
+    if (threadIdx.x == 0) {
+        if (MODE == 2) __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // release: write back for the other XCDs
+        const unsigned target = epoch * n_wg;
+        unsigned spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > max_spins || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        gb_ok = good;
+        if (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave: drop stale cache lines before reading other workgroups' data
+    return gb_ok != 0;
+}
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

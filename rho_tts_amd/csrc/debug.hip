@@ -9,6 +9,19 @@ __global__ void k_touch(float* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = p[i] * 1.0001f + 1.0f;
 }
+template <int MODE>
+__global__ void k_bench_barrier(unsigned* bar, int n, float* buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (i + blockDim.x) % (gridDim.x * blockDim.x);     // the next workgroup's element
+    float acc = buf[i];
+    for (int e = 1; e <= n; ++e) {
+        if (MODE == 2) st_agent(buf + i, acc + 1.0f); else buf[i] = acc + 1.0f;      // something to publish ...
+        if (!grid_barrier<MODE>(bar, gridDim.x, (unsigned)e, 1u << 20)) return;
+        acc = MODE == 2 ? ld_agent(buf + j) : buf[j];                                 // ... and to fetch
+        if (acc != (float)e && i == 0) bar[2] = 1u;                                   // stale read detector
+    }
+    buf[i] = acc;
+}
 __global__ void k_iota64(int64_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -93,6 +106,8 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 500) { g_col_split = skinny_variant - 500; return RT_OK; }             // 500: automatic sub-tile split, 501/502/504: forced
+    if (skinny_variant >= 400) { g_decode_lanes = skinny_variant - 400; return RT_OK; }          // 40n: n decode lanes
     if (skinny_variant >= 300) { g_pred_nt = skinny_variant - 300; return RT_OK; }               // 300: predictor weights cacheable, 301: nt
     if (skinny_variant >= 200) { g_use_graph = skinny_variant - 200; return RT_OK; }            // 200: eager frames, 201: graph replay
     if (skinny_variant >= 100) { g_decode_col = skinny_variant - 100; return RT_OK; }   // 100: legacy 9-launch decode, 101: column path
@@ -138,7 +153,7 @@ int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t s
 
 // Back-to-back launches of the column-owner GEMM over n_mats weight matrices (> 512 MB in total => HBM-cold).
 int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_norm, int32_t epi, int32_t n_mats, int32_t iters,
-                      double* avg_us) {
+                      double* avg_us, int64_t* stamps8) {
     if (!ctx || !avg_us || M < 1 || M > 32 || N < 64 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_col: bad argument");
     std::lock_guard<std::mutex> g(ctx->mu);
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -152,7 +167,7 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     RT_HIP(ctx, hipMalloc((void**)&out, (size_t)32 * N * 4));
     RT_HIP(ctx, hipMalloc((void**)&act, (size_t)32 * N * 2));
     RT_HIP(ctx, hipMalloc((void**)&rowsq, (size_t)32 * 512 * 4));
-    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)32 * (N / 16 + 1) * 4));
+    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)32 * (N / 4 + 4) * 4));
     RT_HIP(ctx, hipMalloc((void**)&normw, (size_t)std::max(K, N) * 4));
     RT_HIP(ctx, hipMemsetAsync(wbuf, 0x3c, pb * n_mats, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(a, 0x3c, (size_t)32 * K * 4, ctx->stream));
@@ -162,9 +177,12 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     PackedW pw;
     pw.N = N; pw.K = K; pw.Np = (N + 31) / 32 * 32; pw.Kp = K; pw.Np16 = (N + 15) / 16 * 16;
     ColArgs c;
+    c.nt = (a_norm & 2) ? 0 : 1;             // bit 1: cacheable weight loads (hot-cache experiment with n_mats = 1)
+    a_norm &= 1;
     c.A = a; c.post_scale = a_norm; c.rowsq = rowsq; c.rowsq_n = K / 16; c.eps = 1e-6f; c.M = M; c.K = K; c.epi = epi;
     c.next_bf16 = epi == COL_RESID ? act : nullptr; c.next_norm_w = normw;
-    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.rowsq_out = rowsq_out; c.rowsq_out_n = N / 16; c.out_bf16 = act;
+    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.split = col_split_for(epi == COL_SILU ? 1 << 30 : N, ctx->n_cu);
+    c.rowsq_out = rowsq_out; c.rowsq_out_n = N / 16 * c.split; c.out_bf16 = act;
     hipEvent_t e0, e1;
     RT_HIP(ctx, hipEventCreate(&e0));
     RT_HIP(ctx, hipEventCreate(&e1));
@@ -177,6 +195,16 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / iters;
+    if (stamps8 && !rc) {       // one more launch with the in-kernel phase stamps of workgroup 0
+        long long* st = nullptr;
+        RT_HIP(ctx, hipMalloc((void**)&st, 64));
+        RT_HIP(ctx, hipMemsetAsync(st, 0, 64, ctx->stream));
+        c.stamps = st;
+        pw.data16 = wbuf + (pb / 2) * (iters % n_mats);
+        rc = launch_gemm_col(ctx, c, pw);
+        RT_HIP(ctx, hipMemcpy(stamps8, st, 64, hipMemcpyDeviceToHost));
+        (void)hipFree(st);
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(wbuf); (void)hipFree(a); (void)hipFree(out); (void)hipFree(act); (void)hipFree(rowsq); (void)hipFree(rowsq_out); (void)hipFree(normw);
     return rc;
@@ -260,6 +288,43 @@ int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(items); (void)hipFree(out); (void)hipFree(st);
     return rc;
+}
+
+// Grid-barrier microbenchmark: one persistent launch of `wgs` x `threads`, n barriers; microseconds per barrier (and the
+// abort flag: non-zero = the grid was not co-resident or a spin bound was hit).
+int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, int32_t mode, double* us_per_barrier, int32_t* aborted) {
+    if (!ctx || !us_per_barrier || wgs < 1 || threads < 64 || threads > 1024 || n < 1) return RT_ERR_INVALID;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int per_cu = 0;
+    auto kern = mode == 2 ? k_bench_barrier<2> : (mode == 1 ? k_bench_barrier<1> : k_bench_barrier<0>);
+    RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
+    if ((int64_t)per_cu * ctx->n_cu < wgs) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_grid_barrier: %d workgroups cannot be co-resident (%d per CU x %d CUs)", wgs, per_cu, ctx->n_cu);
+    unsigned* bar = nullptr;
+    float* buf = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&bar, 64));
+    RT_HIP(ctx, hipMalloc((void**)&buf, (size_t)wgs * threads * 4));
+    RT_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)wgs * threads * 4, ctx->stream));
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        RT_HIP(ctx, hipMemsetAsync(bar, 0, 64, ctx->stream));
+        RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)wgs * threads * 4, ctx->stream));
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, ctx->stream, bar, n, buf);
+        RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    }
+    unsigned h[3] = {0, 0, 0};
+    RT_HIP(ctx, hipMemcpy(h, bar, 12, hipMemcpyDeviceToHost));
+    if (aborted) *aborted = (int32_t)(h[1] | (h[2] << 1));     // bit 0: spin bound hit, bit 1: a stale value was read
+    *us_per_barrier = (double)ms * 1e3 / n;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(bar); (void)hipFree(buf);
+    return RT_OK;
 }
 
 }  // extern "C"

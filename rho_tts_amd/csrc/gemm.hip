@@ -453,6 +453,8 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
 
 int g_pred_nt = 0;              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
 int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
+int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
+int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
 int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
 int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
 int g_skinny_waves_per_cu = 4;  // split-K is chosen so that about this many waves per CU stream weights

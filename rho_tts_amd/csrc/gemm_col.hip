@@ -51,7 +51,10 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     constexpr int C = (NB == 2) ? 4 : 8;     // k-tiles (32 deep) per super-chunk
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, qd = lane >> 4;
-    const int nt = blockIdx.x;
+    const int sp_shift = g.split == 4 ? 2 : (g.split == 2 ? 1 : 0);
+    const int nt = blockIdx.x >> sp_shift, sub = blockIdx.x & (g.split - 1);
+    const int cw_shift = 4 - sp_shift;                        // log2 of the columns this workgroup owns
+    const bool b_mine = (r >> cw_shift) == sub;               // lane holds a B column of this workgroup's sub-tile
     const int kchunk = (g.KT + WAVES - 1) / WAVES;
     const int kt_lo = w * kchunk;
     int kt_hi = kt_lo + kchunk;
@@ -82,12 +85,16 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             int k = sc * C + u;
             if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
 #pragma unroll
-            for (int b = 0; b < NB; ++b) ck.b[b][u] = g.nt ? __builtin_nontemporal_load(wp[b] + (int64_t)k * 64) : wp[b][(int64_t)k * 64];
+            for (int b = 0; b < NB; ++b) {
+                const s8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                ck.b[b][u] = !b_mine ? zero : (g.nt ? __builtin_nontemporal_load(wp[b] + (int64_t)k * 64) : wp[b][(int64_t)k * 64]);
+            }
             ck.a[0][u] = ap[0][(int64_t)k * 64];      // 64 lanes x 16 B = the next contiguous KiB of the sub-block
             ck.a[1][u] = ap[1][(int64_t)k * 64];
         }
     };
 
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[0] = wall_clock64();
     Chunk c0, c1;
     if (n_sc > 0) issue(0, c0);
     // the output element this thread finishes in the epilogue: sub-block mt, accumulator register i, lane l
@@ -95,7 +102,8 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     const int e_row = e_mt * 16 + (e_l >> 4) * 4 + e_i;
     const int n = nt * 16 + (e_l & 15);
     float xres = 0.f;
-    if (EPI == COL_RESID && e_row < g.M && n < g.N) xres = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
+    const bool e_mine = ((e_l & 15) >> cw_shift) == sub;
+    if (EPI == COL_RESID && e_row < g.M && n < g.N && e_mine) xres = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
     if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns row 4w + qd, its lanes split the partials
         const int row_i = 4 * w + qd;
         const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
     }
     if (n_sc > 1) issue(1, c1);
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[1] = wall_clock64();
 
     f4acc_t acc[NB][2];
 #pragma unroll
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
     };
     for (int sc = 0; sc < n_sc; sc += 2) {
         consume(sc, c0);
+        if (g.stamps && sc == 0 && blockIdx.x == 0 && tid == 0) g.stamps[2] = wall_clock64();
         if (sc + 2 < n_sc) issue(sc + 2, c0);
         if (sc + 1 < n_sc) {
             consume(sc + 1, c1);
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         }
     }
 
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[3] = wall_clock64();
     // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue (one output per thread)
     float val[NB];
 #pragma unroll
@@ -152,8 +163,9 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
         for (int ww = 0; ww < WAVES; ++ww) s += red[ww][e_mt][e_i][e_l];
         val[b] = s;
     }
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[4] = wall_clock64();
     {
-        const bool ok = e_row < g.M && n < g.N;
+        const bool ok = e_row < g.M && n < g.N && e_mine;
         const float inv = g.post_scale ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
         float v = val[0] * inv;
         if (EPI == COL_STORE) {
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             float sq = xn * xn;                   // a 16-lane group = one row's 16 columns
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-            if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + nt] = sq;
+            if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + blockIdx.x] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
                 const float u = val[NB - 1] * inv;
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
             }
         }
     }
+    if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
 }
 
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
@@ -206,6 +219,14 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 
 }  // namespace
 
+// sub-tile split for an N-wide decode GEMM: enough workgroups to put one on every CU
+int col_split_for(int N, int n_cu) {
+    if (g_col_split == 1 || g_col_split == 2 || g_col_split == 4) return g_col_split;
+    const int tiles = (N + 15) / 16;
+    if (tiles * 2 <= n_cu) return 2;
+    return 1;
+}
+
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.M < 1 || a.M > 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..32 (callers split larger row blocks)", a.M);
     if (w.K != a.K || w.K % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: K mismatch (%d vs %d) or not a multiple of 32", w.K, a.K);
@@ -214,6 +235,8 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
     g.Wp = w.data16;
     g.NT = w.Np16 / 16;
     g.KT = w.K / 32;
+    if (g.split != 1 && g.split != 2 && g.split != 4) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: split %d (1, 2 or 4)", g.split);
+    if (g.epi == COL_SILU) g.split = 1;
     int tiles = g.NT;
     if (g.epi == COL_SILU) {
         if (w.N % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: gate/up width %d not a multiple of 32", w.N);
@@ -223,8 +246,8 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
     } else {
         g.N = w.N;
     }
-    if (g.epi == COL_RESID && (!g.rowsq_out || g.rowsq_out_n < g.NT)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: rowsq_out too small");
+    if (g.epi == COL_RESID && (!g.rowsq_out || g.rowsq_out_n < g.NT * g.split)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: rowsq_out too small");
     if (g.post_scale && (!g.rowsq || g.rowsq_n < 1)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: row scaling without partials");
     if (g.next_bf16 && !g.next_norm_w) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: next operand without its norm weight");
-    return dispatch_epi(ctx, g, dim3(tiles), ev_start, ev_stop);
+    return dispatch_epi(ctx, g, dim3(tiles * g.split), ev_start, ev_stop);
 }

@@ -69,6 +69,9 @@ int skinny_pick_split(int M, int N, int K, int n_cu);
 extern int g_decode_col;
 extern int g_use_graph;
 extern int g_pred_nt;
+extern int g_decode_lanes;
+extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
+int col_split_for(int N, int n_cu);
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
 extern int g_skinny_waves_per_cu;
 
@@ -86,6 +89,8 @@ struct ColArgs {
     float eps = 0.f;
     int M = 0, K = 0;
     int epi = COL_STORE;
+    int split = 1;                  // 1, 2 or 4 workgroups per 16-column tile (each owns 16/split columns): spreads a narrow GEMM
+                                    // (N/16 < number of CUs) over more CUs; RESID then emits NT*split rowsq partials per row
     float* out = nullptr;           // STORE: out [M][ldc] f32 row-major;  RESID: tiled f32 residual stream, updated in place
     bf16_t* next_bf16 = nullptr;    // RESID: tiled bf16(next_norm_w .* x_new), the operand of the GEMM behind the next RMSNorm
     const float* next_norm_w = nullptr;
@@ -95,6 +100,7 @@ struct ColArgs {
     float* rowsq_out = nullptr;     // RESID: [M][rowsq_out_n] sums of squares of the new x per 32-column tile
     int rowsq_out_n = 0;
     bf16_t* out_bf16 = nullptr;     // SILU: act [M][ldc]
+    long long* stamps = nullptr;    // debug: 100-MHz wall-clock stamps of workgroup 0 at the phase boundaries
     // filled by the launcher
     const bf16_t* Wp = nullptr;
     int NT = 0, KT = 0, N = 0, up_tile_offset = 0;

@@ -111,7 +111,10 @@ struct rt_model {
     // decode-frame graphs (A: LM head + sample + residual-code predictor, B: next input + talker step), reused while the
     // launch signature (every pointer and parameter baked into the nodes) stays the same
     uint64_t graph_sig = 0;
-    hipGraphExec_t graph_a = nullptr, graph_b = nullptr;
+    std::vector<hipGraphExec_t> graphs;            // [lane][A, B]
+    std::vector<hipStream_t> lane_streams;         // decode lanes (created on first use)
+    std::vector<hipEvent_t> lane_events;
+    hipEvent_t fork_event = nullptr;
     int64_t weight_bytes = 0;
 
     bool has_mtp() const { return cfg.talker.hidden != cfg.predictor.hidden; }
@@ -396,14 +399,14 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
                  int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
-    const int H = d.hidden, NTh = H / 16, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
+    const int H = d.hidden, sp_h = col_split_for(H, ctx->n_cu), NTh = H / 16 * sp_h, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
     const bool isp = &S == &m->pred;
     for (int i = 0; i < d.layers; ++i) {
         LayerW& L = S.L[i];
         const float* next_w = (i + 1 < d.layers) ? S.L[i + 1].ln1 : S.norm;   // the norm that reads x after this layer
         ColArgs a;      // qkv = rmsnorm(x; ln1) Wqkv^T : operand w.xa = bf16(ln1 .* x), row scale from rowsq
         a.A = w.xa; a.post_scale = 1; a.rowsq = rowsq; a.rowsq_n = NTh; a.eps = d.rms_eps; a.M = M; a.K = H;
-        a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw;
+        a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw; a.split = col_split_for(qw, ctx->n_cu);
         RT_TRY(col_gemm(m, a, L.wqkv, isp));
         if (one_row_per_slot) {
             RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
@@ -415,7 +418,7 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         }
         ColArgs o;      // x += ls1 .* (ao Wo^T); emits rowsq and bf16(ln2 .* x) for the MLP
         o.A = w.ao; o.M = M; o.K = d.heads * d.head_dim; o.epi = COL_RESID; o.out = x; o.ldc = H; o.scale = L.ls1;
-        o.rowsq_out = rowsq; o.rowsq_out_n = NTh; o.next_bf16 = w.xa; o.next_norm_w = L.ln2;
+        o.rowsq_out = rowsq; o.rowsq_out_n = NTh; o.next_bf16 = w.xa; o.next_norm_w = L.ln2; o.split = sp_h;
         RT_TRY(col_gemm(m, o, L.wo, isp));
         ColArgs gu;     // act = silu(g) * u with [g; u] = rmsnorm(x; ln2) Wgu^T
         gu.A = w.xa; gu.post_scale = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.M = M; gu.K = H;
@@ -423,7 +426,7 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         RT_TRY(col_gemm(m, gu, L.wgu, isp));
         ColArgs dn;     // x += ls2 .* (act Wd^T); emits rowsq and bf16(next norm .* x)
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
-        dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w;
+        dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w; dn.split = sp_h;
         RT_TRY(col_gemm(m, dn, L.wd, isp));
     }
     return RT_OK;
@@ -435,7 +438,7 @@ int col_head(rt_model* m, const bf16_t* xa, const float* rowsq, int rowsq_n, int
              const PackedW& W, const float* bias, float* out) {
     ColArgs a;
     a.A = xa; a.post_scale = 1; a.rowsq = rowsq; a.rowsq_n = rowsq_n; a.eps = eps; a.M = M; a.K = K; a.row_off = row_off;
-    a.epi = COL_STORE; a.out = out - (size_t)row_off * W.N; a.ldc = W.N; a.bias = bias;
+    a.epi = COL_STORE; a.out = out - (size_t)row_off * W.N; a.ldc = W.N; a.bias = bias; a.split = col_split_for(W.N, m->ctx->n_cu);
     return col_gemm(m, a, W);
 }
 
@@ -519,8 +522,10 @@ int rt_model_destroy(rt_model* m) {
     if (m->pad_t) (void)hipFree(m->pad_t);
     if (m->d_frame_srcs) (void)hipFree(m->d_frame_srcs);
     for (auto& e : m->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    if (m->graph_a) (void)hipGraphExecDestroy(m->graph_a);
-    if (m->graph_b) (void)hipGraphExecDestroy(m->graph_b);
+    for (auto ex : m->graphs) if (ex) (void)hipGraphExecDestroy(ex);
+    for (auto st : m->lane_streams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto ev : m->lane_events) (void)hipEventDestroy(ev);
+    if (m->fork_event) (void)hipEventDestroy(m->fork_event);
     delete m;
     return RT_OK;
 }
@@ -834,40 +839,14 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(alloc_stack_ws(m, c.talker, n_suffix, &w));
         RT_TRY(stack_forward(m, m->talker, w, x, n_suffix, d_slot, d_pos, 0, nullptr, hn_all_f32));
     }
-    // ---- decode state
-    const int B2 = 2 * B;
-    float *xt, *hn_f32, *xp, *logits;
-    bf16_t *hn, *hn_p;
-    int32_t *d_codes, *d_eos, *d_slot_b, *d_pos_b, *d_pos_p2, *d_zero_pos, *d_forced = nullptr, *d_tmp_idx;
-    int64_t* d_items;
-    uint8_t* d_seen;
-    RT_TRY(pool_arr(m, (size_t)B * H, &xt));
-    RT_TRY(pool_arr(m, (size_t)B * H, &hn_f32));
-    RT_TRY(pool_arr(m, (size_t)B * H, &hn));
-    RT_TRY(pool_arr(m, (size_t)B2 * Hp, &xp));
-    RT_TRY(pool_arr(m, (size_t)B2 * Hp, &hn_p));
-    RT_TRY(pool_arr(m, (size_t)64 * 32768, &logits));
+    // ---- decode state.  The batch is cut into `lanes` groups of consecutive items, each decoding on its own stream with
+    // its own workspaces: a decode step is a chain of ~600 short dependent kernels whose cost is latency, not bytes, so two
+    // chains in flight overlap each other's launch/drain gaps (items are independent: same results for any lane count).
+    int32_t *d_codes, *d_eos, *d_forced = nullptr;
     RT_TRY(pool_arr(m, (size_t)T_max * B * G, &d_codes));
     RT_TRY(pool_arr(m, (size_t)T_max * B, &d_eos));
-    RT_TRY(pool_arr(m, B2, &d_slot_b));
-    RT_TRY(pool_arr(m, B, &d_pos_b));
-    RT_TRY(pool_arr(m, B2, &d_pos_p2));
-    RT_TRY(pool_arr(m, B2, &d_zero_pos));
-    RT_TRY(pool_arr(m, B2, &d_tmp_idx));
-    RT_TRY(pool_arr(m, B, &d_items));
-    RT_TRY(pool_arr(m, (size_t)B * Vc, &d_seen));
-    RT_HIP(ctx, hipMemsetAsync(d_seen, 0, (size_t)B * Vc, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(d_codes, 0, (size_t)T_max * B * G * 4, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(d_eos, 0, (size_t)T_max * B * 4, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(d_zero_pos, 0, B2 * 4, ctx->stream));
-    {
-        std::vector<int32_t> sl(B2), p2(B2);
-        for (int b = 0; b < B; ++b) { sl[b] = b; sl[B + b] = b; p2[b] = 0; p2[B + b] = 1; }
-        RT_HIP(ctx, hipMemcpyAsync(d_slot_b, sl.data(), B2 * 4, hipMemcpyHostToDevice, ctx->stream));
-        RT_HIP(ctx, hipMemcpyAsync(d_pos_p2, p2.data(), B2 * 4, hipMemcpyHostToDevice, ctx->stream));
-        RT_HIP(ctx, hipMemcpyAsync(d_pos_b, P.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
-        RT_HIP(ctx, hipMemcpyAsync(d_items, A->h_item_ids, B * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
     std::vector<int32_t> forced_host;
     if (A->h_forced_codes) {
         if (!A->h_forced_offsets) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: forced codes without offsets");
@@ -886,134 +865,197 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(pool_arr(m, forced_host.size(), &d_forced));
         RT_HIP(ctx, hipMemcpyAsync(d_forced, forced_host.data(), forced_host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    // decode state.  Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
-    const bool col = g_decode_col && B2 <= 64 && m->has_mtp() && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 &&
-                     c.predictor.inter % 32 == 0;   // (equal-width predictor: the legacy path materialises the past hidden)
-    const int NTt = H / 16, NTp = Hp / 16;
-    float *rowsq_t = nullptr, *rowsq_p = nullptr, *x_all = x;
-    DecWs dwt, dwp;
-    StackWs wt, wp;
-    if (col) {
-        RT_TRY(pool_arr(m, (size_t)B * NTt, &rowsq_t));
-        RT_TRY(pool_arr(m, (size_t)B2 * NTp, &rowsq_p));
-        RT_TRY(alloc_dec_ws(m, c.talker, B, &dwt));
-        RT_TRY(alloc_dec_ws(m, c.predictor, B2, &dwp));
-        // xt <- residual-stream rows (before the final norm) of each item's last prompt position
-        RT_TRY(launch_gather_f32(ctx, x_all, H, d_last, B, xt, nullptr));
-        // (the prompt's last rows are already the talker's OUTPUT: their next consumer is the final norm)
-        RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT, dwt.xa, m->talker.norm));
-    } else {
-        // hn <- final-norm rows of each item's last prompt position
-        RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last, B, hn_f32, hn));
-        RT_TRY(alloc_stack_ws(m, c.talker, B, &wt));
-        RT_TRY(alloc_stack_ws(m, c.predictor, B2, &wp));
-    }
-    const PackedW& head = PW(m, "talker.codec_head");
-
-    int32_t* d_frame = nullptr;
     uint64_t* d_seed = nullptr;
-    RT_TRY(pool_arr(m, 1, &d_frame));
     RT_TRY(pool_arr(m, 1, &d_seed));
-    RT_HIP(ctx, hipMemsetAsync(d_frame, 0, 4, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(d_seed, &A->seed, 8, hipMemcpyHostToDevice, ctx->stream));
     const int64_t codes_fs = (int64_t)B * G;
+    // Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
+    const bool col = g_decode_col && 2 * B <= 64 && m->has_mtp() && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 &&
+                     c.predictor.inter % 32 == 0;   // (equal-width predictor: the legacy path materialises the past hidden)
+    const int NTt = H / 16 * col_split_for(H, ctx->n_cu), NTp = Hp / 16 * col_split_for(Hp, ctx->n_cu);   // rowsq partials per row
+    const PackedW& head = PW(m, "talker.codec_head");
+    float* x_all = x;
+
+    struct Lane {
+        int b0 = 0, n = 0;
+        hipStream_t stream = nullptr;
+        float *xt = nullptr, *hn_f32 = nullptr, *xp = nullptr, *logits = nullptr, *rowsq_t = nullptr, *rowsq_p = nullptr;
+        bf16_t *hn = nullptr, *hn_p = nullptr;
+        int32_t *d_slot_b = nullptr, *d_pos_b = nullptr, *d_pos_p2 = nullptr, *d_zero_pos = nullptr, *d_frame = nullptr;
+        int64_t* d_items = nullptr;
+        uint8_t* d_seen = nullptr;
+        DecWs dwt, dwp;
+        StackWs wt, wp;
+        bool done = false;
+    };
+    int n_lanes = std::max(1, std::min(g_decode_lanes, 8));
+    if (!col || m->prof) n_lanes = 1;                      // (per-launch profiling wants undisturbed launches)
+    while (n_lanes > 1 && B / n_lanes < 8) --n_lanes;      // a lane narrower than 8 rows only multiplies the weight traffic
+    std::vector<Lane> lanes(n_lanes);
+    hipStream_t main_stream = ctx->stream;
+    struct StreamGuard { rt_ctx* c; hipStream_t s; ~StreamGuard() { c->stream = s; } } stream_guard{ctx, main_stream};
+    if (n_lanes > 1) {
+        while ((int)m->lane_streams.size() < n_lanes) {
+            hipStream_t st = nullptr;
+            RT_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            m->lane_streams.push_back(st);
+            hipEvent_t ev = nullptr;
+            RT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            m->lane_events.push_back(ev);
+        }
+        if (!m->fork_event) RT_HIP(ctx, hipEventCreateWithFlags(&m->fork_event, hipEventDisableTiming));
+    }
+    for (int l = 0; l < n_lanes; ++l) {
+        Lane& ln = lanes[l];
+        ln.b0 = (int)((int64_t)B * l / n_lanes);
+        ln.n = (int)((int64_t)B * (l + 1) / n_lanes) - ln.b0;
+        ln.stream = n_lanes > 1 ? m->lane_streams[l] : main_stream;
+        const int n = ln.n, n2 = 2 * n;
+        RT_TRY(pool_arr(m, (size_t)n * H, &ln.xt));
+        RT_TRY(pool_arr(m, (size_t)n * H, &ln.hn_f32));
+        RT_TRY(pool_arr(m, (size_t)n * H, &ln.hn));
+        RT_TRY(pool_arr(m, (size_t)n2 * Hp, &ln.xp));
+        RT_TRY(pool_arr(m, (size_t)n2 * Hp, &ln.hn_p));
+        RT_TRY(pool_arr(m, (size_t)64 * 32768, &ln.logits));
+        RT_TRY(pool_arr(m, n2, &ln.d_slot_b));
+        RT_TRY(pool_arr(m, n, &ln.d_pos_b));
+        RT_TRY(pool_arr(m, n2, &ln.d_pos_p2));
+        RT_TRY(pool_arr(m, n2, &ln.d_zero_pos));
+        RT_TRY(pool_arr(m, n, &ln.d_items));
+        RT_TRY(pool_arr(m, (size_t)n * Vc, &ln.d_seen));
+        RT_TRY(pool_arr(m, 1, &ln.d_frame));
+        RT_HIP(ctx, hipMemsetAsync(ln.d_seen, 0, (size_t)n * Vc, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(ln.d_zero_pos, 0, n2 * 4, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(ln.d_frame, 0, 4, ctx->stream));
+        std::vector<int32_t> sl(n2), p2(n2);
+        for (int b = 0; b < n; ++b) { sl[b] = ln.b0 + b; sl[n + b] = ln.b0 + b; p2[b] = 0; p2[n + b] = 1; }
+        RT_HIP(ctx, hipMemcpyAsync(ln.d_slot_b, sl.data(), n2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(ln.d_pos_p2, p2.data(), n2 * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(ln.d_pos_b, P.data() + ln.b0, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(ln.d_items, A->h_item_ids + ln.b0, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (sl / p2 are stack-local staging)
+        if (col) {
+            RT_TRY(pool_arr(m, (size_t)n * NTt, &ln.rowsq_t));
+            RT_TRY(pool_arr(m, (size_t)n2 * NTp, &ln.rowsq_p));
+            RT_TRY(alloc_dec_ws(m, c.talker, n, &ln.dwt));
+            RT_TRY(alloc_dec_ws(m, c.predictor, n2, &ln.dwp));
+            // xt <- residual-stream rows (before the final norm) of each item's last prompt position
+            RT_TRY(launch_gather_f32(ctx, x_all, H, d_last + ln.b0, n, ln.xt, nullptr));
+            // (the prompt's last rows are already the talker's OUTPUT: their next consumer is the final norm)
+            RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.norm));
+        } else {
+            // hn <- final-norm rows of each item's last prompt position
+            RT_TRY(launch_gather_f32(ctx, hn_all_f32, H, d_last + ln.b0, n, ln.hn_f32, ln.hn));
+            RT_TRY(alloc_stack_ws(m, c.talker, n, &ln.wt));
+            RT_TRY(alloc_stack_ws(m, c.predictor, n2, &ln.wp));
+        }
+    }
 
     // ---- frame part A: group 0 from the talker state, then the residual-code predictor.  Every frame-dependent address
     // is base + *d_frame * stride resolved on the device, so the same launches (or one captured graph) serve every frame.
-    auto enqueue_a = [&]() -> int {
+    auto enqueue_a = [&](Lane& ln) -> int {
+        const int n = ln.n, n2 = 2 * n;
+        int32_t* codes = d_codes + (size_t)ln.b0 * G;
         int ns = 0;
-        if (col) { RT_TRY(col_head(m, dwt.xa, rowsq_t, NTt, 0, B, H, c.talker.rms_eps, head, nullptr, logits)); ns = 1; }
-        else RT_TRY(gemm_rows(m, hn, B, head, logits, &ns));
+        if (col) { RT_TRY(col_head(m, ln.dwt.xa, ln.rowsq_t, NTt, 0, n, H, c.talker.rms_eps, head, nullptr, ln.logits)); ns = 1; }
+        else RT_TRY(gemm_rows(m, ln.hn, n, head, ln.logits, &ns));
         SampleArgs sa{};
-        sa.logits = logits; sa.n_slabs = ns; sa.M = B; sa.V = Vc;
+        sa.logits = ln.logits; sa.n_slabs = ns; sa.M = n; sa.V = Vc;
         sa.do_sample = A->talker.do_sample; sa.temperature = A->talker.temperature; sa.top_k = A->talker.top_k; sa.top_p = A->talker.top_p;
-        sa.rep_penalty = A->talker.repetition_penalty; sa.seen = d_seen;
+        sa.rep_penalty = A->talker.repetition_penalty; sa.seen = ln.d_seen;
         sa.suppress_from = c.codebook_size; sa.allow_token = -1;
-        sa.seed_ptr = d_seed; sa.item_ids = d_items; sa.frame = 0; sa.group = 0;
-        sa.forced = d_forced; sa.forced_fs = (int64_t)G * B;
-        sa.out = d_codes; sa.out_stride = G; sa.out_fs = codes_fs; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos; sa.eos_fs = B;
-        sa.logits_copy = A->d_trace_talker; sa.copy_fs = (int64_t)B * Vc;
-        sa.frame_ptr = d_frame; sa.eos_live = A->ignore_eos ? 0 : 1; sa.min_frames = A->min_frames;
+        sa.seed_ptr = d_seed; sa.item_ids = ln.d_items; sa.frame = 0; sa.group = 0;
+        sa.forced = d_forced ? d_forced + ln.b0 : nullptr; sa.forced_fs = (int64_t)G * B;
+        sa.out = codes; sa.out_stride = G; sa.out_fs = codes_fs; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos + ln.b0; sa.eos_fs = B;
+        sa.logits_copy = A->d_trace_talker ? A->d_trace_talker + (size_t)ln.b0 * Vc : nullptr; sa.copy_fs = (int64_t)B * Vc;
+        sa.frame_ptr = ln.d_frame; sa.eos_live = A->ignore_eos ? 0 : 1; sa.min_frames = A->min_frames;
         RT_TRY(launch_sample(ctx, sa));
-        // predictor: rows [0,B) = past hidden (pos 0), rows [B,2B) = embedding of code 0 (pos 1)
+        // predictor: rows [0,n) = past hidden (pos 0), rows [n,2n) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
-            if (col) RT_TRY(col_head(m, dwt.xa, rowsq_t, NTt, 0, B, H, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), xp));
+            if (col) RT_TRY(col_head(m, ln.dwt.xa, ln.rowsq_t, NTt, 0, n, H, c.talker.rms_eps, PW(m, "pred.mtp"), VEC(m, "pred.mtp_b"), ln.xp));
             else {
-                RT_TRY(gemm_rows(m, hn, B, PW(m, "pred.mtp"), logits, &ns));
-                RT_TRY(launch_reduce_slabs(ctx, logits, ns, B, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, xp, nullptr));
+                RT_TRY(gemm_rows(m, ln.hn, n, PW(m, "pred.mtp"), ln.logits, &ns));
+                RT_TRY(launch_reduce_slabs(ctx, ln.logits, ns, n, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, ln.xp, nullptr));
             }
-            RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, d_codes, B, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
+            RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, codes, n, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
         } else {
-            RT_HIP(ctx, hipMemcpyAsync(xp, hn_f32, (size_t)B * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, d_codes, B, H, nullptr, nullptr, nullptr, xp + (size_t)B * Hp, nullptr, G, d_frame, codes_fs));
+            RT_HIP(ctx, hipMemcpyAsync(ln.xp, ln.hn_f32, (size_t)n * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, codes, n, H, nullptr, nullptr, nullptr, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
         }
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xp, B2, Hp, rowsq_p, NTp, dwp.xT, dwp.xa, m->pred.L[0].ln1));
-            RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B2, d_slot_b, d_pos_p2, 0, false));
+            RT_TRY(launch_rowsq(ctx, ln.xp, n2, Hp, ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
+            RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n2, ln.d_slot_b, ln.d_pos_p2, 0, false));
         } else {
-            RT_TRY(stack_forward(m, m->pred, wp, xp, B2, d_slot_b, d_pos_p2, 0, hn_p, nullptr));
+            RT_TRY(stack_forward(m, m->pred, ln.wp, ln.xp, n2, ln.d_slot_b, ln.d_pos_p2, 0, ln.hn_p, nullptr));
         }
         for (int q = 0; q < G - 1; ++q) {
-            const size_t roff = (q == 0) ? (size_t)B : 0;      // the first head reads the rows of position 1
+            const size_t roff = (q == 0) ? (size_t)n : 0;      // the first head reads the rows of position 1
             if (col) {
-                RT_TRY(col_head(m, dwp.xa, rowsq_p, NTp, (int)roff, B, Hp, c.predictor.rms_eps,
-                                PW(m, "pred.head" + std::to_string(q)), nullptr, logits));
+                RT_TRY(col_head(m, ln.dwp.xa, ln.rowsq_p, NTp, (int)roff, n, Hp, c.predictor.rms_eps,
+                                PW(m, "pred.head" + std::to_string(q)), nullptr, ln.logits));
                 ns = 1;
             } else {
-                RT_TRY(gemm_rows(m, hn_p + roff * Hp, B, PW(m, "pred.head" + std::to_string(q)), logits, &ns));
+                RT_TRY(gemm_rows(m, ln.hn_p + roff * Hp, n, PW(m, "pred.head" + std::to_string(q)), ln.logits, &ns));
             }
             SampleArgs sp{};
-            sp.logits = logits; sp.n_slabs = ns; sp.M = B; sp.V = Vp;
+            sp.logits = ln.logits; sp.n_slabs = ns; sp.M = n; sp.V = Vp;
             sp.do_sample = A->predictor.do_sample; sp.temperature = A->predictor.temperature; sp.top_k = A->predictor.top_k;
             sp.top_p = A->predictor.top_p; sp.rep_penalty = 1.0f; sp.seen = nullptr; sp.suppress_from = Vp; sp.allow_token = -1;
-            sp.seed_ptr = d_seed; sp.item_ids = d_items; sp.frame = 0; sp.group = q + 1;
-            sp.forced = d_forced ? d_forced + (size_t)(q + 1) * B : nullptr; sp.forced_fs = (int64_t)G * B;
-            sp.out = d_codes + q + 1; sp.out_stride = G; sp.out_fs = codes_fs; sp.eos_token = -1; sp.eos_flag = nullptr; sp.eos_fs = 0;
-            sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + (size_t)q * B * Vp : nullptr;
+            sp.seed_ptr = d_seed; sp.item_ids = ln.d_items; sp.frame = 0; sp.group = q + 1;
+            sp.forced = d_forced ? d_forced + (size_t)(q + 1) * B + ln.b0 : nullptr; sp.forced_fs = (int64_t)G * B;
+            sp.out = codes + q + 1; sp.out_stride = G; sp.out_fs = codes_fs; sp.eos_token = -1; sp.eos_flag = nullptr; sp.eos_fs = 0;
+            sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + ((size_t)q * B + ln.b0) * Vp : nullptr;
             sp.copy_fs = (int64_t)(G - 1) * B * Vp;
-            sp.frame_ptr = d_frame; sp.eos_live = 0; sp.min_frames = 0;
+            sp.frame_ptr = ln.d_frame; sp.eos_live = 0; sp.min_frames = 0;
             RT_TRY(launch_sample(ctx, sp));
             if (q < G - 2) {
-                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, d_codes + q + 1, B, xp, nullptr, G, d_frame, codes_fs));
-                else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, d_codes + q + 1, B, H, nullptr, nullptr, nullptr, xp, nullptr, G, d_frame, codes_fs));
+                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));
+                else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, codes + q + 1, n, H, nullptr, nullptr, nullptr, ln.xp, nullptr, G, ln.d_frame, codes_fs));
                 if (col) {
-                    RT_TRY(launch_rowsq(ctx, xp, B, Hp, rowsq_p, NTp, dwp.xT, dwp.xa, m->pred.L[0].ln1));
-                    RT_TRY(stack_decode(m, m->pred, dwp, dwp.xT, rowsq_p, B, d_slot_b, d_zero_pos, q + 2));
+                    RT_TRY(launch_rowsq(ctx, ln.xp, n, Hp, ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
+                    RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n, ln.d_slot_b, ln.d_zero_pos, q + 2));
                 } else {
-                    RT_TRY(stack_forward(m, m->pred, wp, xp, B, d_slot_b, d_zero_pos, q + 2, hn_p, nullptr));
+                    RT_TRY(stack_forward(m, m->pred, ln.wp, ln.xp, n, ln.d_slot_b, ln.d_zero_pos, q + 2, ln.hn_p, nullptr));
                 }
             }
         }
         return RT_OK;
     };
     // ---- frame part B: next talker input (sum of the frame's G code embeddings + projected tts_pad), talker step, frame += 1
-    auto enqueue_b = [&]() -> int {
-        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_codes, B, H, pad_t, nullptr, nullptr, xt, nullptr, G, d_frame, codes_fs));
+    auto enqueue_b = [&](Lane& ln) -> int {
+        const int n = ln.n;
+        int32_t* codes = d_codes + (size_t)ln.b0 * G;
+        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes, n, H, pad_t, nullptr, nullptr, ln.xt, nullptr, G, ln.d_frame, codes_fs));
         if (col) {
-            RT_TRY(launch_rowsq(ctx, xt, B, H, rowsq_t, NTt, dwt.xT, dwt.xa, m->talker.L[0].ln1));
-            RT_TRY(stack_decode(m, m->talker, dwt, dwt.xT, rowsq_t, B, d_slot_b, d_pos_b, 0, true, d_frame));
+            RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.L[0].ln1));
+            RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, 0, true, ln.d_frame));
         } else {
-            RT_TRY(stack_forward(m, m->talker, wt, xt, B, d_slot_b, d_pos_b, 0, hn, hn_f32, d_frame));
+            RT_TRY(stack_forward(m, m->talker, ln.wt, ln.xt, n, ln.d_slot_b, ln.d_pos_b, 0, ln.hn, ln.hn_f32, ln.d_frame));
         }
-        hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, d_frame);
+        hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, ln.d_frame);
         RT_HIP(ctx, hipGetLastError());
         return RT_OK;
     };
 
-    // ---- graphs: capture A and B once per launch signature, replay per frame (1.5-1.8 us per dependent kernel instead of
-    // the ~3 us an eager launch costs on the host: tools/bench_launch.py)
+    // ---- graphs: capture A and B once per lane and launch signature, replay per frame
     bool use_graph = g_use_graph && !m->prof;
     if (use_graph) {
         uint64_t sig = 1469598103934665603ull;
         auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
-        for (const void* p : {(const void*)xt, (const void*)xp, (const void*)logits, (const void*)d_codes, (const void*)d_eos, (const void*)d_seen,
-                              (const void*)d_forced, (const void*)A->d_trace_talker, (const void*)A->d_trace_predictor, (const void*)pad_t,
-                              (const void*)d_frame, (const void*)d_seed, (const void*)d_items, (const void*)d_slot_b, (const void*)d_pos_b,
-                              (const void*)rowsq_t, (const void*)rowsq_p, (const void*)dwt.xT, (const void*)dwp.xT, (const void*)dwt.xa, (const void*)dwp.xa, (const void*)dwt.qkv, (const void*)dwp.qkv, (const void*)dwt.act,
-                              (const void*)dwp.act, (const void*)wt.slabs, (const void*)wp.slabs, (const void*)hn, (const void*)hn_p,
-                              (const void*)ctx->stream})
+        for (const void* p : {(const void*)d_codes, (const void*)d_eos, (const void*)d_forced, (const void*)A->d_trace_talker,
+                              (const void*)A->d_trace_predictor, (const void*)pad_t, (const void*)d_seed})
             mix((uint64_t)(uintptr_t)p);
-        mix(B); mix(col); mix(A->ignore_eos); mix(A->min_frames);
+        for (const Lane& ln : lanes)
+            for (const void* p : {(const void*)ln.xt, (const void*)ln.xp, (const void*)ln.logits, (const void*)ln.d_seen, (const void*)ln.d_frame,
+                                  (const void*)ln.d_items, (const void*)ln.d_slot_b, (const void*)ln.d_pos_b, (const void*)ln.d_pos_p2,
+                                  (const void*)ln.d_zero_pos, (const void*)ln.rowsq_t, (const void*)ln.rowsq_p, (const void*)ln.dwt.xT,
+                                  (const void*)ln.dwp.xT, (const void*)ln.dwt.xa, (const void*)ln.dwp.xa, (const void*)ln.dwt.qkv,
+                                  (const void*)ln.dwp.qkv, (const void*)ln.dwt.act, (const void*)ln.dwp.act, (const void*)ln.wt.slabs,
+                                  (const void*)ln.wp.slabs, (const void*)ln.hn, (const void*)ln.hn_p, (const void*)ln.hn_f32, (const void*)ln.stream}) {
+                mix((uint64_t)(uintptr_t)p);
+                mix(ln.b0); mix(ln.n);
+            }
+        mix(B); mix(col); mix(n_lanes); mix(A->ignore_eos); mix(A->min_frames);
         for (const rt_sampling* sp : {&A->talker, &A->predictor}) {
             mix(sp->do_sample); mix(sp->top_k);
             uint32_t f;
@@ -1021,30 +1063,39 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             memcpy(&f, &sp->top_p, 4); mix(f);
             memcpy(&f, &sp->repetition_penalty, 4); mix(f);
         }
-        if (sig != m->graph_sig || !m->graph_a || !m->graph_b) {
-            if (m->graph_a) { (void)hipGraphExecDestroy(m->graph_a); m->graph_a = nullptr; }
-            if (m->graph_b) { (void)hipGraphExecDestroy(m->graph_b); m->graph_b = nullptr; }
+        if (sig != m->graph_sig || (int)m->graphs.size() != 2 * n_lanes) {
+            for (auto ex : m->graphs) if (ex) (void)hipGraphExecDestroy(ex);
+            m->graphs.clear();
             m->graph_sig = 0;
-            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            for (int which = 0; which < 2; ++which) {
-                hipGraph_t gr = nullptr;
-                RT_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                const int rc = which == 0 ? enqueue_a() : enqueue_b();
-                const hipError_t ce = hipStreamEndCapture(ctx->stream, &gr);
-                if (rc || ce != hipSuccess) {
-                    if (gr) (void)hipGraphDestroy(gr);
-                    return rc ? rc : rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph capture failed: %s", hipGetErrorString(ce));
+            RT_HIP(ctx, hipStreamSynchronize(main_stream));
+            for (int l = 0; l < n_lanes; ++l) {
+                for (int which = 0; which < 2; ++which) {
+                    hipGraph_t gr = nullptr;
+                    ctx->stream = lanes[l].stream;
+                    RT_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                    const int rc = which == 0 ? enqueue_a(lanes[l]) : enqueue_b(lanes[l]);
+                    const hipError_t ce = hipStreamEndCapture(ctx->stream, &gr);
+                    ctx->stream = main_stream;
+                    if (rc || ce != hipSuccess) {
+                        if (gr) (void)hipGraphDestroy(gr);
+                        return rc ? rc : rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph capture failed: %s", hipGetErrorString(ce));
+                    }
+                    hipGraphExec_t ex = nullptr;
+                    const hipError_t ie = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(gr);
+                    if (ie != hipSuccess) return rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph instantiate failed: %s", hipGetErrorString(ie));
+                    m->graphs.push_back(ex);
                 }
-                hipGraphExec_t ex = nullptr;
-                const hipError_t ie = hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(gr);
-                if (ie != hipSuccess) return rt_fail(ctx, RT_ERR_HIP, "rt_generate: graph instantiate failed: %s", hipGetErrorString(ie));
-                (which == 0 ? m->graph_a : m->graph_b) = ex;
             }
             m->graph_sig = sig;
         }
     }
 
+    // ---- fork: the lane streams start after everything enqueued so far (prompt prefill, state set-up)
+    if (n_lanes > 1) {
+        RT_HIP(ctx, hipEventRecord(m->fork_event, main_stream));
+        for (Lane& ln : lanes) RT_HIP(ctx, hipStreamWaitEvent(ln.stream, m->fork_event, 0));
+    }
     std::vector<int32_t> eos_host((size_t)T_max * B, 0);
     std::vector<char> done(B, 0);
     std::vector<int> produced(B, 0);
@@ -1052,26 +1103,50 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     bool cancelled = false;
     for (int t = 0; t < T_max; ++t) {
         if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
-        if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graph_a, ctx->stream));
-        else RT_TRY(enqueue_a());
+        for (int l = 0; l < n_lanes; ++l) {
+            Lane& ln = lanes[l];
+            if (ln.done) continue;
+            ctx->stream = ln.stream;
+            if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l], ln.stream));
+            else RT_TRY(enqueue_a(ln));
+            if (!A->ignore_eos)
+                RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)t * B + ln.b0, d_eos + (size_t)t * B + ln.b0, ln.n * 4, hipMemcpyDeviceToHost, ln.stream));
+        }
+        ctx->stream = main_stream;
         frames_run = t + 1;
         // ---- stop bookkeeping (needs the eos flags on the host only when eos is live)
+        if (!A->ignore_eos)
+            for (Lane& ln : lanes) if (!ln.done) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         bool all_done = true;
-        if (!A->ignore_eos) {
-            RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)t * B, d_eos + (size_t)t * B, B * 4, hipMemcpyDeviceToHost, ctx->stream));
-            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        for (int b = 0; b < B; ++b) {
-            if (!done[b]) {
-                if (eos_host[(size_t)t * B + b]) done[b] = 1;
-                else if (++produced[b] >= A->h_max_frames[b]) done[b] = 1;
+        for (Lane& ln : lanes) {
+            if (ln.done) continue;
+            bool lane_done = true;
+            for (int b = ln.b0; b < ln.b0 + ln.n; ++b) {
+                if (!done[b]) {
+                    if (eos_host[(size_t)t * B + b]) done[b] = 1;
+                    else if (++produced[b] >= A->h_max_frames[b]) done[b] = 1;
+                }
+                lane_done = lane_done && done[b];
             }
-            all_done = all_done && done[b];
+            ln.done = lane_done;
+            all_done = all_done && lane_done;
         }
         if (all_done) break;
-        if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graph_b, ctx->stream));
-        else RT_TRY(enqueue_b());
+        for (int l = 0; l < n_lanes; ++l) {
+            Lane& ln = lanes[l];
+            if (ln.done) continue;
+            ctx->stream = ln.stream;
+            if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l + 1], ln.stream));
+            else RT_TRY(enqueue_b(ln));
+        }
+        ctx->stream = main_stream;
     }
+    // ---- join
+    if (n_lanes > 1)
+        for (int l = 0; l < n_lanes; ++l) {
+            RT_HIP(ctx, hipEventRecord(m->lane_events[l], lanes[l].stream));
+            RT_HIP(ctx, hipStreamWaitEvent(main_stream, m->lane_events[l], 0));
+        }
     // ---- results
     std::vector<int32_t> codes_host((size_t)std::max(frames_run, 1) * B * G);
     if (frames_run > 0) {

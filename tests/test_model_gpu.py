@@ -187,3 +187,43 @@ def test_legacy_and_column_decode_paths_agree(models):
         if key == "talker":
             a, b = a[..., :V0], b[..., :V0]
         assert float((a - b).abs().max()) <= 0.06 * float(a.std()) + 1e-6      # each is within 4 % of the oracle
+
+
+def test_decode_lanes_and_tile_split_do_not_change_results(ctx):
+    """Items are independent, so cutting the batch into concurrently decoding lanes (rt_debug_tune 40n) must leave every
+    code unchanged; splitting a 16-column GEMM tile over 2 or 4 workgroups (50n) only regroups the RMSNorm partial sums."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg = config.PRESETS["tiny"]()
+    nm, _ = build(ctx, cfg, max_batch=16)
+    try:
+        set_voice(nm, make_voice(cfg, True))
+        g = torch.Generator().manual_seed(3)
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(n),), generator=g)] for n in torch.randint(1, 9, (16,), generator=g)]
+        frames = [int(v) for v in torch.randint(3, 8, (16,), generator=g)]
+        sp = RtSampling(1, 0.9, 50, 1.0, 1.05)
+        lib = nm.lib
+        base, tr0 = nm.generate(texts, frames, sp, seed=77, trace=True)
+        try:
+            lib.rt_debug_tune(402, 0)
+            two, tr2 = nm.generate(texts, frames, sp, seed=77, trace=True)
+        finally:
+            lib.rt_debug_tune(401, 0)
+        assert all(torch.equal(a, b) for a, b in zip(base, two))
+        for key in ("talker", "predictor"):
+            assert torch.equal(tr0[key], tr2[key])
+        outs = {}
+        try:
+            for code in (501, 502, 504):
+                lib.rt_debug_tune(code, 0)
+                _, outs[code] = nm.generate(texts, frames, RtSampling(0, 1, 1, 1, 1), forced_codes=base, trace=True)
+        finally:
+            lib.rt_debug_tune(500, 0)
+        V0 = cfg.codec.codebook_size
+        for code in (502, 504):
+            for key in ("talker", "predictor"):
+                a, b = outs[501][key].cpu(), outs[code][key].cpu()
+                if key == "talker":
+                    a, b = a[..., :V0], b[..., :V0]
+                assert float((a - b).abs().max()) <= 1e-3 * float(a.std()) + 1e-6
+    finally:
+        nm.close()
