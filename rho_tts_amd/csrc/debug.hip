@@ -189,7 +189,10 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     int rc = RT_OK;
     for (int i = 0; i < n_mats && !rc; ++i) { pw.data16 = wbuf + (pb / 2) * i; rc = launch_gemm_col(ctx, c, pw); }
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < iters && !rc; ++i) { pw.data16 = wbuf + (pb / 2) * (i % n_mats); rc = launch_gemm_col(ctx, c, pw); }
+    for (int i = 0; i < iters && !rc; ++i) {
+        pw.data16 = wbuf + (pb / 2) * (i % n_mats);
+        rc = launch_gemm_col(ctx, c, pw);
+    }
     RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;

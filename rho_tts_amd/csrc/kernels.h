@@ -110,6 +110,13 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
 int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr,
                  bf16_t* a_tiled = nullptr, const float* norm_w = nullptr);
 
+// decode-step input: x = add_vec + sum of n_src (<= 16) bf16 embedding rows (or one row of f32_table), emitted as tiled x,
+// tiled bf16(norm_w .* x) and rowsq - the fusion of launch_gather_sum / launch_gather_f32 with launch_rowsq
+struct GatherSrc;
+int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const float* f32_table, const int32_t* d_idx, int idx_stride,
+                       const int32_t* frame_ptr, int64_t idx_frame_stride, int M, int H, const float* add_vec, float* rowsq, int rowsq_n,
+                       float* x_tiled, bf16_t* a_tiled, const float* norm_w);
+
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
 //   x += scale[:] * sum_s slab[s]   (slab stride M*H; scale may be null)

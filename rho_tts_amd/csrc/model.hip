@@ -1009,10 +1009,12 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             sp.frame_ptr = ln.d_frame; sp.eos_live = 0; sp.min_frames = 0;
             RT_TRY(launch_sample(ctx, sp));
             if (q < G - 2) {
-                if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));
+                if (col) {      // (col implies has_mtp)
+                    RT_TRY(launch_embed_rowsq(ctx, nullptr, 0, m->proj_emb[q], codes + q + 1, G, ln.d_frame, codes_fs, n, Hp, nullptr, ln.rowsq_p,
+                                              NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
+                } else if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));
                 else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, codes + q + 1, n, H, nullptr, nullptr, nullptr, ln.xp, nullptr, G, ln.d_frame, codes_fs));
                 if (col) {
-                    RT_TRY(launch_rowsq(ctx, ln.xp, n, Hp, ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
                     RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n, ln.d_slot_b, ln.d_zero_pos, q + 2));
                 } else {
                     RT_TRY(stack_forward(m, m->pred, ln.wp, ln.xp, n, ln.d_slot_b, ln.d_zero_pos, q + 2, ln.hn_p, nullptr));
@@ -1025,9 +1027,14 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     auto enqueue_b = [&](Lane& ln) -> int {
         const int n = ln.n;
         int32_t* codes = d_codes + (size_t)ln.b0 * G;
-        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes, n, H, pad_t, nullptr, nullptr, ln.xt, nullptr, G, ln.d_frame, codes_fs));
+        if (col && G <= 16) {
+            RT_TRY(launch_embed_rowsq(ctx, m->d_frame_srcs, G, nullptr, codes, G, ln.d_frame, codes_fs, n, H, pad_t, ln.rowsq_t, NTt, ln.dwt.xT,
+                                      ln.dwt.xa, m->talker.L[0].ln1));
+        } else {
+            RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes, n, H, pad_t, nullptr, nullptr, ln.xt, nullptr, G, ln.d_frame, codes_fs));
+            if (col) RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.L[0].ln1));
+        }
         if (col) {
-            RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.L[0].ln1));
             RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, 0, true, ln.d_frame));
         } else {
             RT_TRY(stack_forward(m, m->talker, ln.wt, ln.xt, n, ln.d_slot_b, ln.d_pos_b, 0, ln.hn, ln.hn_f32, ln.d_frame));

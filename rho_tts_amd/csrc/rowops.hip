@@ -94,6 +94,76 @@ __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int 
     for (int j = threadIdx.x; j < rowsq_n; j += 256) rowsq[row * rowsq_n + j] = j == 0 ? tot : 0.f;
 }
 
+// Decode-step input in one launch: row = add_vec + sum_j table_j[idx_j] (bf16 embedding rows, summed in source order) or
+// one row of an f32 table, written straight in the column path's layouts - fragment-tiled f32 x, tiled bf16(norm_w .* x)
+// and the RMSNorm sum of squares (rowsq[row][0], the other partial slots zeroed).  Replaces k_gather_* + k_rowsq: all
+// embedding rows of a thread are loaded before the first add (one memory round trip instead of n_src dependent ones).
+__global__ __launch_bounds__(256) void k_embed_rowsq(const GatherSrc* __restrict__ srcs, int n_src, const float* __restrict__ f32_table,
+                                                     const int32_t* __restrict__ idx, int idx_stride,
+                                                     const int32_t* __restrict__ frame_ptr, int64_t idx_frame_stride, int H,
+                                                     const float* __restrict__ add_vec, float* __restrict__ rowsq, int rowsq_n,
+                                                     float* __restrict__ x_tiled, bf16_t* __restrict__ a_tiled,
+                                                     const float* __restrict__ norm_w) {
+    constexpr int MAXS = 16;
+    __shared__ const bf16_t* sh_tab[MAXS];
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (frame_ptr) idx += (int64_t)(*frame_ptr) * idx_frame_stride;
+    if (tid < MAXS) {
+        const bf16_t* p = nullptr;
+        if (tid < n_src) {
+            const int id = idx[(int64_t)row * idx_stride + tid];
+            if (id >= 0) p = srcs[tid].table + (int64_t)id * srcs[tid].row_stride;
+        }
+        sh_tab[tid] = p;
+    }
+    const int fid = f32_table ? idx[(int64_t)row * idx_stride] : -1;
+    __syncthreads();
+    float ss = 0.f;
+    for (int c = tid * 8; c < H; c += 2048) {
+        uint4 raw[MAXS];
+#pragma unroll
+        for (int j = 0; j < MAXS; ++j) {
+            const bf16_t* p = sh_tab[j];
+            raw[j] = p ? *reinterpret_cast<const uint4*>(p + c) : uint4{0u, 0u, 0u, 0u};
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = add_vec ? add_vec[c + e] : 0.f;
+        if (fid >= 0) {
+            const f4_t a = *reinterpret_cast<const f4_t*>(f32_table + (int64_t)fid * H + c);
+            const f4_t b = *reinterpret_cast<const f4_t*>(f32_table + (int64_t)fid * H + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXS; ++j) {
+            if (sh_tab[j]) {              // (a missing source adds nothing - not even +0.0 - exactly like k_gather_sum)
+                const unsigned wds[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __uint_as_float(wds[e] << 16);
+                    v[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        const int64_t o = tile_off(row, c, H);
+        *reinterpret_cast<f4_t*>(x_tiled + o) = f4_t{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f4_t*>(x_tiled + o + 4) = f4_t{v[4], v[5], v[6], v[7]};
+        const f4_t w0 = *reinterpret_cast<const f4_t*>(norm_w + c), w1 = *reinterpret_cast<const f4_t*>(norm_w + c + 4);
+        uint4 pk;
+        pk.x = f32x2_to_bf16x2(w0[0] * v[0], w0[1] * v[1]);
+        pk.y = f32x2_to_bf16x2(w0[2] * v[2], w0[3] * v[3]);
+        pk.z = f32x2_to_bf16x2(w1[0] * v[4], w1[1] * v[5]);
+        pk.w = f32x2_to_bf16x2(w1[2] * v[6], w1[3] * v[7]);
+        *reinterpret_cast<uint4*>(a_tiled + o) = pk;
+    }
+    const float tot = block_sum_f32(ss, sh);
+    for (int j = tid; j < rowsq_n; j += 256) rowsq[(int64_t)row * rowsq_n + j] = j == 0 ? tot : 0.f;
+}
+
 __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
                            int64_t total4) {
     const int I4 = I >> 2;
@@ -317,6 +387,18 @@ int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int ro
                  const float* norm_w) {
     if (M <= 0) return RT_OK;
     hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const float* f32_table, const int32_t* d_idx, int idx_stride,
+                       const int32_t* frame_ptr, int64_t idx_frame_stride, int M, int H, const float* add_vec, float* rowsq, int rowsq_n,
+                       float* x_tiled, bf16_t* a_tiled, const float* norm_w) {
+    if (M <= 0) return RT_OK;
+    if (n_src > 16 || H % 8 || !x_tiled || !a_tiled || !norm_w || !rowsq || rowsq_n < 1 || (n_src > 0 && !d_srcs))
+        return rt_fail(ctx, RT_ERR_INVALID, "embed_rowsq: n_src %d (<= 16), H %d (multiple of 8) or a missing buffer", n_src, H);
+    hipLaunchKernelGGL(k_embed_rowsq, dim3(M), dim3(256), 0, ctx->stream, d_srcs, n_src, f32_table, d_idx, idx_stride, frame_ptr,
+                       idx_frame_stride, H, add_vec, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
