@@ -168,6 +168,15 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_gemm_col", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": None, "launches": int(n_l),
                     "avg_launch_us": round(ms * 1e3 / n_l, 3), "avg_bytes_per_launch": round(by / n_l, 1)}
+            # HBM-side bytes per launch: the PMC pass cannot run inside this process, so the committed FETCH_SIZE measurement
+            # of the same kernel on the same GEMM shapes (profiles/r01_d_pmc_ratio.json) scales the algorithmic bytes
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_ratio.json")) as f:
+                    pmc = json.load(f)
+                roof["traffic"] = round(by / n_l * float(pmc["ratio"]), 1)
+                roof["traffic_source"] = "FETCH_SIZE (x2 gfx950 correction) / algorithmic = %.4f, %s" % (pmc["ratio"], pmc["file"])
+            except (OSError, KeyError, ValueError):
+                pass
         # decode-step view: algorithmic bytes per frame for the local batch
         t_, p_ = cfg.talker, cfg.predictor
         w_talker = 2 * (t_.weight_params() + t_.hidden * cfg.codec_vocab)
