@@ -106,6 +106,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 600) { g_tile96 = skinny_variant - 600; return RT_OK; }                 // 600/601: 128x96 tiles off/on
     if (skinny_variant >= 500) { g_col_split = skinny_variant - 500; return RT_OK; }             // 500: automatic sub-tile split, 501/502/504: forced
     if (skinny_variant >= 400) { g_decode_lanes = skinny_variant - 400; return RT_OK; }          // 40n: n decode lanes
     if (skinny_variant >= 300) { g_pred_nt = skinny_variant - 300; return RT_OK; }               // 300: predictor weights cacheable, 301: nt
@@ -181,7 +182,7 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     a_norm &= 1;
     c.A = a; c.post_scale = a_norm; c.rowsq = rowsq; c.rowsq_n = K / 16; c.eps = 1e-6f; c.M = M; c.K = K; c.epi = epi;
     c.next_bf16 = epi == COL_RESID ? act : nullptr; c.next_norm_w = normw;
-    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.split = col_split_for(epi == COL_SILU ? 1 << 30 : N, ctx->n_cu);
+    c.out = out; c.ldc = epi == COL_SILU ? N / 2 : N; c.split = epi == COL_SILU ? col_split_silu(N, ctx->n_cu) : col_split_for(N, ctx->n_cu);
     c.rowsq_out = rowsq_out; c.rowsq_out_n = N / 16 * c.split; c.out_bf16 = act;
     hipEvent_t e0, e1;
     RT_HIP(ctx, hipEventCreate(&e0));

@@ -224,16 +224,21 @@ __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B ro
 // SPLIT: the f32 A operand is fed as two bf16 planes, hi = bf16(x) and lo = bf16(x - hi), and every B fragment
 // is multiplied with both (2x MFMA work): products stay exact, activation precision goes from 2^-9 to ~2^-17.
 // Used by the codec decoder, whose waveform has to agree with the f32-activation oracle to RMSE < 1e-3.
-template <bool A_F32, bool SPLIT>
+// Waves are arranged WGM x WGN, each computing MT x NTT 32x32 tiles: the workgroup tile is (WGM*MT*32) x (WGN*NTT*32).
+// 2,2,2,2 = 128 x 128 (default); 4,1,1,3 = 128 x 96 for the codec decoder's 96- and 192-channel stages, where a 128-wide
+// tile would spend a quarter of its MFMAs on padding columns.
+template <bool A_F32, bool SPLIT, int WGM, int WGN, int MT, int NTT>
 __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
+    static_assert(WGM * WGN == 4 && WGM * MT * 32 == BM, "4 waves, 128 rows");
+    constexpr int BNT = WGN * NTT * 32;
     constexpr int PLANES = SPLIT ? 2 : 1;
     constexpr int BUF = BM * 64 * PLANES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WGN, wn = w % WGN;
     const int r = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * BM;   // x: row tiles (can exceed 65535), y: column tiles
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BNT;
     const int kt0 = blockIdx.z * g.kt_per_split;
     int kt1 = kt0 + g.kt_per_split;
     if (kt1 > g.KT) kt1 = g.KT;
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 }
             } else {
                 dst = *reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.a.ptr) + off);
+                if (SPLIT) dst_lo = *reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.a.ptr_lo) + off);
             }
         } else {
 #pragma unroll
@@ -306,10 +312,10 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
         if (SPLIT) *reinterpret_cast<s8_t*>(lds + buf * BUF + BM * 64 + lds_a_off(p >> 2, p & 3)) = v_lo;
     };
     // ---- B fragments straight from the packed weights (global -> VGPR), one 16-B load per (nt, kt)
-    const int nt_base = (n0 >> 5) + wn * 2;
-    auto load_b = [&](int it, s8_t (&b)[2][2]) {
+    const int nt_base = (n0 >> 5) + wn * NTT;
+    auto load_b = [&](int it, s8_t (&b)[NTT][2]) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int t_n = nt_base + nt, t_k = kt0 + it * 2 + kk;
@@ -322,15 +328,15 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
             }
     };
 
-    f16_t acc[2][2];
+    f16_t acc[MT][NTT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NTT; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    s8_t ra[2], rl[2], rb[2][2], rb_next[2][2];
+    s8_t ra[2], rl[2], rb[NTT][2], rb_next[NTT][2];
     load_piece(0, ra[0], rl[0]);
     load_piece(1, ra[1], rl[1]);
     load_b(0, rb);
@@ -346,20 +352,20 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
             load_piece(1, ra[1], rl[1]);
             load_b(it + 1, rb_next);
         }
-        s8_t fa[2][2], fl[2][2];
+        s8_t fa[MT][2], fl[MT][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
-                if (SPLIT) fl[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + BM * 64 + lds_a_off(wm * 64 + mt * 32 + r, kk * 2 + h));
+                fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + lds_a_off((wm * MT + mt) * 32 + r, kk * 2 + h));
+                if (SPLIT) fl[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * BUF + BM * 64 + lds_a_off((wm * MT + mt) * 32 + r, kk * 2 + h));
             }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NTT; ++nt) {
                     acc[mt][nt] = mfma32(fa[mt][kk], rb[nt][kk], acc[mt][nt]);
                     if (SPLIT) acc[mt][nt] = mfma32(fl[mt][kk], rb[nt][kk], acc[mt][nt]);
                 }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
             store_piece(0, buf ^ 1, ra[0], rl[0]);
             store_piece(1, buf ^ 1, ra[1], rl[1]);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) rb[nt][kk] = rb_next[nt][kk];
         }
@@ -379,21 +385,29 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
     const int64_t M = g.a.M;
     float* slab = e.out_f32 ? e.out_f32 + (int64_t)blockIdx.z * M * e.ldc : nullptr;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wn * 64 + nt * 32 + r;
+        for (int nt = 0; nt < NTT; ++nt) {
+            const int n = n0 + (wn * NTT + nt) * 32 + r;
             if (n >= g.N) continue;
             float bias = 0.f, scale = 1.f, sa = 0.f, sib = 0.f, s2a = 0.f, s2ib = 0.f;
             if (e.split_k == 1) {
                 if (e.bias) bias = e.bias[n];
                 if (e.scale) scale = e.scale[n];
                 if (e.act == ACT_SNAKE) { sa = e.snake_a[n]; sib = e.snake_ib[n]; }
-                if (e.out2_bf16 || e.out2_f32) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
+                if (e.out2_bf16 || e.out2_f32 || e.out2_hi) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
+            }
+            // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads left
+            // inside the store loop would be serialised behind every earlier store - 64 dependent round trips per thread
+            float res[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = m0 + (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                res[i] = (e.residual && e.split_k == 1 && m < M) ? e.residual[m * e.ldc + n] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int64_t m = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int64_t m = m0 + (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (m >= M) continue;
                 float v = acc[mt][nt][i];
                 const int64_t o = m * e.ldc + n;
@@ -404,9 +418,21 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
                 else if (e.act == ACT_SNAKE) { const float s = __sinf(v * sa); v = v + sib * s * s; }
                 else if (e.act == ACT_CLAMP1) v = fminf(1.f, fmaxf(-1.f, v));
                 v *= scale;
-                if (e.residual) v += e.residual[o];
+                if (e.residual) v += res[i];
                 if (e.out_f32) e.out_f32[o] = v;
                 if (e.out_bf16) e.out_bf16[o] = f32_to_bf16(v);
+                if (e.out_hi) {
+                    const bf16_t hi = f32_to_bf16(v);
+                    e.out_hi[o] = hi;
+                    e.out_lo[o] = f32_to_bf16(v - bf16_to_f32(hi));
+                }
+                if (e.out2_hi) {
+                    const float s = __sinf(v * s2a);
+                    const float v2 = v + s2ib * s * s;
+                    const bf16_t hi = f32_to_bf16(v2);
+                    e.out2_hi[o] = hi;
+                    e.out2_lo[o] = f32_to_bf16(v2 - bf16_to_f32(hi));
+                }
                 if (e.out2_bf16 || e.out2_f32) {
                     const float s = __sinf(v * s2a);
                     const float v2 = v + s2ib * s * s;
@@ -453,6 +479,7 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
 
 int g_pred_nt = 0;              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
 int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
+int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
 int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
@@ -518,11 +545,23 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     g.kt_per_split = per;
     const int64_t my = (a.M + BM - 1) / BM;
     if (my > 0x7fffffff) return rt_fail(ctx, RT_ERR_LENGTH, "gemm: length %lld rows too large", (long long)a.M);
-    dim3 grid((unsigned)my, (w.N + BN - 1) / BN, e.split_k);
-    if (a.split && !a.is_f32) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand");
-    if (a.split) hipLaunchKernelGGL((k_gemm_tiled<true, true>), grid, dim3(256), 0, ctx->stream, g);
-    else if (a.is_f32) hipLaunchKernelGGL((k_gemm_tiled<true, false>), grid, dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL((k_gemm_tiled<false, false>), grid, dim3(256), 0, ctx->stream, g);
+    // 96-wide workgroup tiles when N is a multiple of 96 but not of 128 (the decoder's 96- and 192-channel stages)
+    const bool narrow = g_tile96 && e.split_k == 1 && w.N % 96 == 0 && w.N % 128 != 0;
+    const int bn = narrow ? 96 : BN;
+    dim3 grid((unsigned)my, (w.N + bn - 1) / bn, e.split_k);
+    if (a.split && !a.is_f32 && !a.ptr_lo) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand or a low plane");
+    if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || !e.snake2_a || !e.snake2_ib)) || ((e.out_hi || e.out2_hi) && e.split_k > 1))
+        return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");
+#define RT_TILED(AF, SP)                                                                                          \
+    do {                                                                                                          \
+        if (narrow) hipLaunchKernelGGL((k_gemm_tiled<AF, SP, 4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);   \
+        else hipLaunchKernelGGL((k_gemm_tiled<AF, SP, 2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);          \
+    } while (0)
+    if (a.split && !a.is_f32) RT_TILED(false, true);
+    else if (a.split) RT_TILED(true, true);
+    else if (a.is_f32) RT_TILED(true, false);
+    else RT_TILED(false, false);
+#undef RT_TILED
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

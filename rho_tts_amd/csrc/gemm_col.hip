@@ -219,6 +219,14 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 
 }  // namespace
 
+// gate/up GEMM (N = 2 * inter): a workgroup owns a gate tile and its up tile, N/32 workgroups.  Halving the tiles to even out
+// the 1.5 rounds of the 1.7B talker (384 workgroups on 256 CUs) was measured slower (21.5 vs 17.4 us: every workgroup
+// re-reads the whole A operand), so the split is only taken when forced through rt_debug_tune(502/504).
+int col_split_silu(int N, int n_cu) {
+    (void)N; (void)n_cu;
+    return (g_col_split == 2 || g_col_split == 4) ? g_col_split : 1;
+}
+
 // sub-tile split for an N-wide decode GEMM: enough workgroups to put one on every CU
 int col_split_for(int N, int n_cu) {
     if (g_col_split == 1 || g_col_split == 2 || g_col_split == 4) return g_col_split;
@@ -236,7 +244,6 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
     g.NT = w.Np16 / 16;
     g.KT = w.K / 32;
     if (g.split != 1 && g.split != 2 && g.split != 4) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: split %d (1, 2 or 4)", g.split);
-    if (g.epi == COL_SILU) g.split = 1;
     int tiles = g.NT;
     if (g.epi == COL_SILU) {
         if (w.N % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: gate/up width %d not a multiple of 32", w.N);

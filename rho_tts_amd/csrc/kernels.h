@@ -23,8 +23,10 @@ struct PackedW {
 // zero outside [0, T_in).  A plain matrix is taps = 1, rows_out = rows_in = M.
 struct GemmA {
     const void* ptr = nullptr;
+    const void* ptr_lo = nullptr;   // split with a bf16 source: the low plane (same layout as ptr), written by the producer's epilogue
     int is_f32 = 0;        // 1: float32 source converted to bf16 on load; 0: bf16
-    int split = 0;         // 1 (f32 source only): feed hi + lo bf16 planes, ~f32 activation precision at 2x MFMA work
+    int split = 0;         // 1: feed hi + lo bf16 planes, ~f32 activation precision at 2x MFMA work.  f32 source: split on load
+                           //    (per consuming workgroup and tap); bf16 source: ptr / ptr_lo are the planes, split once by the producer
     int64_t M = 0;
     int Cin = 0;           // K = taps * Cin, Cin % 8 == 0
     int taps = 1;
@@ -50,6 +52,10 @@ struct GemmEpi {
     const float* snake_ib = nullptr;     // 1 / (exp(beta) + 1e-9)
     bf16_t* out2_bf16 = nullptr;
     float* out2_f32 = nullptr;
+    bf16_t* out_hi = nullptr;            // out as hi + lo bf16 planes (hi = bf16(v), lo = bf16(v - hi)): the split operand of the next GEMM
+    bf16_t* out_lo = nullptr;
+    bf16_t* out2_hi = nullptr;           // the same for out2
+    bf16_t* out2_lo = nullptr;
     const float* snake2_a = nullptr;
     const float* snake2_ib = nullptr;
     int64_t ldc = 0;
@@ -70,8 +76,10 @@ extern int g_decode_col;
 extern int g_use_graph;
 extern int g_pred_nt;
 extern int g_decode_lanes;
+extern int g_tile96;
 extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
 int col_split_for(int N, int n_cu);
+int col_split_silu(int N, int n_cu);
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
 extern int g_skinny_waves_per_cu;
 

@@ -422,7 +422,7 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         RT_TRY(col_gemm(m, o, L.wo, isp));
         ColArgs gu;     // act = silu(g) * u with [g; u] = rmsnorm(x; ln2) Wgu^T
         gu.A = w.xa; gu.post_scale = 1; gu.rowsq = rowsq; gu.rowsq_n = NTh; gu.eps = d.rms_eps; gu.M = M; gu.K = H;
-        gu.epi = COL_SILU; gu.out_bf16 = w.act; gu.ldc = d.inter;
+        gu.epi = COL_SILU; gu.out_bf16 = w.act; gu.ldc = d.inter; gu.split = col_split_silu(2 * d.inter, ctx->n_cu);
         RT_TRY(col_gemm(m, gu, L.wgu, isp));
         ColArgs dn;     // x += ls2 .* (act Wd^T); emits rowsq and bf16(next norm .* x)
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
@@ -1249,12 +1249,21 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         cur = up;
     }
     // ---- decoder: conv k7 -> [SnakeBeta, transposed conv, 3 residual units] x n -> SnakeBeta -> conv k7 -> clamp
-    float* s_in = nullptr;  // snake-activated input of the next transposed conv
+    // The snake-activated operands (s_in, s1, s2) are kept as hi + lo bf16 planes written by the producing epilogue: the same
+    // 4 bytes per element as f32, but the split is done once per element instead of once per consuming workgroup and tap.
+    struct Planes { bf16_t* hi = nullptr; bf16_t* lo = nullptr; };
+    auto planes = [&](size_t n, Planes* p) -> int {
+        RT_TRY(pool_arr(m, n, &p->hi));
+        RT_TRY(pool_arr(m, n, &p->lo));
+        return RT_OK;
+    };
+    Planes s_in;  // snake-activated input of the next transposed conv
     {
-        RT_TRY(pool_arr(m, (size_t)B * Tc * m->dec_ch[0], &s_in));
+        RT_TRY(planes((size_t)B * Tc * m->dec_ch[0], &s_in));
         GemmA a; a.ptr = cur; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = Hc; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
         a.rows_out = (int)Tc; a.rows_in = (int)Tc;
-        GemmEpi e; e.bias = VEC(m, "codec.dec0_b"); e.out2_f32 = s_in; e.snake2_a = VEC(m, "codec.b0.sa"); e.snake2_ib = VEC(m, "codec.b0.sib");
+        GemmEpi e; e.bias = VEC(m, "codec.dec0_b"); e.out2_hi = s_in.hi; e.out2_lo = s_in.lo;
+        e.snake2_a = VEC(m, "codec.b0.sa"); e.snake2_ib = VEC(m, "codec.b0.sib");
         e.ldc = m->dec_ch[0];
         RT_TRY(launch_gemm(ctx, a, PW(m, "codec.dec0"), e));
     }
@@ -1264,15 +1273,16 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         const int64_t To = (Tc - 1) * r;
         if (To < 1) return rt_fail(ctx, RT_ERR_LENGTH, "rt_code2wav: length collapsed in decoder block %d", i);
         const int64_t rows = (int64_t)B * To;
-        float *xr = nullptr, *s1 = nullptr, *s2 = nullptr;
+        float* xr = nullptr;
+        Planes s1, s2;
         RT_TRY(pool_arr(m, (size_t)rows * cout, &xr));
-        RT_TRY(pool_arr(m, (size_t)rows * cout, &s1));
-        RT_TRY(pool_arr(m, (size_t)rows * cout, &s2));
+        RT_TRY(planes((size_t)rows * cout, &s1));
+        RT_TRY(planes((size_t)rows * cout, &s2));
         {
             // transposed conv k = 2r, stride r, r samples trimmed on both sides: out[m*r + j] = x[m+1] W[j] + x[m] W[j + r]
-            GemmA a; a.ptr = s_in; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * (Tc - 1); a.Cin = cin; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
+            GemmA a; a.ptr = s_in.hi; a.ptr_lo = s_in.lo; a.split = 1; a.M = (int64_t)B * (Tc - 1); a.Cin = cin; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
             a.rows_out = (int)(Tc - 1); a.rows_in = (int)Tc;
-            GemmEpi e; e.bias = VEC(m, bn + ".tconv_b"); e.out_f32 = xr; e.out2_f32 = s1;
+            GemmEpi e; e.bias = VEC(m, bn + ".tconv_b"); e.out_f32 = xr; e.out2_hi = s1.hi; e.out2_lo = s1.lo;
             e.snake2_a = m->xvec[bn + ".u0.a1"]; e.snake2_ib = m->xvec[bn + ".u0.ib1"];
             e.ldc = (int64_t)r * cout;
             RT_TRY(launch_gemm(ctx, a, PW(m, bn + ".tconv"), e));
@@ -1280,13 +1290,13 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         for (int j = 0; j < 3; ++j) {
             const std::string u = bn + ".u" + std::to_string(j);
             const int dil = j == 0 ? 1 : (j == 1 ? 3 : 9);
-            GemmA a; a.ptr = s1; a.is_f32 = 1; a.split = 1; a.M = rows; a.Cin = cout; a.taps = 7; a.tap_stride = dil; a.tap_offset = -6 * dil;
+            GemmA a; a.ptr = s1.hi; a.ptr_lo = s1.lo; a.split = 1; a.M = rows; a.Cin = cout; a.taps = 7; a.tap_stride = dil; a.tap_offset = -6 * dil;
             a.rows_out = (int)To; a.rows_in = (int)To;
             GemmEpi e; e.bias = VEC(m, u + ".c1_b"); e.act = ACT_SNAKE; e.snake_a = VEC(m, u + ".a2"); e.snake_ib = VEC(m, u + ".ib2");
-            e.out_f32 = s2; e.ldc = cout;
+            e.out_hi = s2.hi; e.out_lo = s2.lo; e.ldc = cout;
             RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e));
-            GemmA a2; a2.ptr = s2; a2.is_f32 = 1; a2.split = 1; a2.M = rows; a2.Cin = cout;
-            GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_f32 = s1; e2.ldc = cout;
+            GemmA a2; a2.ptr = s2.hi; a2.ptr_lo = s2.lo; a2.split = 1; a2.M = rows; a2.Cin = cout;
+            GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_hi = s1.hi; e2.out2_lo = s1.lo; e2.ldc = cout;
             if (j < 2) { e2.snake2_a = VEC(m, bn + ".u" + std::to_string(j + 1) + ".a1"); e2.snake2_ib = VEC(m, bn + ".u" + std::to_string(j + 1) + ".ib1"); }
             else if (i + 1 < c.n_upsample_rates) { e2.snake2_a = VEC(m, "codec.b" + std::to_string(i + 1) + ".sa"); e2.snake2_ib = VEC(m, "codec.b" + std::to_string(i + 1) + ".sib"); }
             else { e2.snake2_a = VEC(m, "codec.fin_a"); e2.snake2_ib = VEC(m, "codec.fin_ib"); }
@@ -1301,7 +1311,7 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         // last conv: channels -> 1, k = 7, causal, then clamp(-1, 1): the 7 x C taps of one output sample are contiguous
         // in the channels-last buffer, so it is the same implicit GEMM with a single output column
         const int cl = m->dec_ch.back();
-        GemmA a; a.ptr = s_in; a.is_f32 = 1; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = cl; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
+        GemmA a; a.ptr = s_in.hi; a.ptr_lo = s_in.lo; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = cl; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
         a.rows_out = (int)Tc; a.rows_in = (int)Tc;
         GemmEpi e; e.bias = VEC(m, "codec.fin_b"); e.act = ACT_CLAMP1; e.out_f32 = wav_tmp; e.ldc = 1;
         RT_TRY(launch_gemm(ctx, a, PW(m, "codec.fin_w"), e));
