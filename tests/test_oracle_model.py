@@ -162,3 +162,52 @@ def test_rope_table_matches_formula():
     cos, sin = rope_table(8, 10000.0, 5)
     assert cos.shape == (5, 4) and float(cos[0].min()) == 1.0
     assert abs(float(sin[3, 1]) - np.sin(3 * 10000.0 ** (-2 / 8))) < 1e-6
+
+
+def test_predictor_recurrence_matches_transformers_sibling(tiny_model):
+    """The residual-code predictor pass (prefill [past hidden, embed(code 0)] -> head 0, then embedding table g-1 -> head g,
+    one KV cache over the frame's 16 positions) == transformers' Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration
+    (modeling_qwen3_omni_moe.py:2534-2608) on the same weights.  The sibling has no mtp projection, so it is fed the projected
+    rows / tables (projection and gather commute row by row)."""
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import Qwen3OmniMoeTalkerCodePredictorConfig
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration
+    from transformers import DynamicCache
+    from oracle.sampling import SamplingParams
+    cfg, m = tiny_model
+    d, W, G = cfg.predictor, m.W, cfg.n_groups
+    hc = Qwen3OmniMoeTalkerCodePredictorConfig(
+        vocab_size=cfg.predictor_vocab, hidden_size=d.hidden, intermediate_size=d.inter, num_hidden_layers=d.layers,
+        num_attention_heads=d.heads, num_key_value_heads=d.kv_heads, head_dim=d.head_dim, rms_norm_eps=d.rms_eps,
+        max_position_embeddings=64, attention_bias=False, num_code_groups=G, sliding_window=None,
+        rope_parameters={"rope_theta": d.rope_theta, "rope_type": "default"})
+    hc._attn_implementation = "eager"
+    sib = Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration(hc).eval()
+
+    def proj(x):
+        return x @ W["predictor.mtp_proj.weight"].T + W["predictor.mtp_proj.bias"] if cfg.has_mtp_proj else x
+
+    sd = {"model." + k[len("predictor."):]: v for k, v in W.items() if k.startswith("predictor.layers.") or k == "predictor.norm.weight"}
+    for g in range(G - 1):
+        sd[f"model.codec_embedding.{g}.weight"] = proj(W[f"predictor.codec_embedding.{g}.weight"])
+        sd[f"lm_head.{g}.weight"] = W[f"predictor.lm_head.{g}.weight"]
+    missing, unexpected = sib.load_state_dict(sd, strict=False)
+    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+
+    B = 3
+    gen = torch.Generator().manual_seed(11)
+    past = torch.randn(B, cfg.talker.hidden, generator=gen) * 0.5
+    c0 = torch.randint(0, cfg.codec.codebook_size, (B,), generator=gen)
+    trace = {}
+    codes = m.predictor_frame(past, c0, SamplingParams(), 0, list(range(B)), 0, trace=trace)      # greedy
+    with torch.no_grad():
+        x = torch.stack([proj(past), proj(m.codec_embed(c0))], dim=1)
+        out = sib(inputs_embeds=x, past_key_values=DynamicCache(config=hc), use_cache=True)
+        ref_logits = [out.logits[:, -1]]
+        ref_codes = [ref_logits[0].argmax(-1)]
+        for g in range(1, G - 1):
+            out = sib(input_ids=ref_codes[-1][:, None], past_key_values=out.past_key_values, use_cache=True, generation_steps=g)
+            ref_logits.append(out.logits[:, -1])
+            ref_codes.append(ref_logits[-1].argmax(-1))
+    for g in range(G - 1):
+        assert float((trace["pred_logits"][g] - ref_logits[g]).abs().max()) < 5e-5, g
+    assert torch.equal(codes[:, 1:], torch.stack(ref_codes, 1))
