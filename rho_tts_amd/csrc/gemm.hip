@@ -380,66 +380,102 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue
+    // ---- epilogue.  Every option of GemmEpi is uniform over the launch, so each one is tested ONCE per 32x32 accumulator
+    // tile with the 16-element loops inside (tested per element, the option branches and 64-bit index arithmetic made the
+    // epilogue ~220 instructions per output - several times the cost of the K loop for the codec decoder's short-K convs).
     const GemmEpi& e = g.e;
-    const int64_t M = g.a.M;
-    float* slab = e.out_f32 ? e.out_f32 + (int64_t)blockIdx.z * M * e.ldc : nullptr;
+    const int64_t M = g.a.M, ldc = e.ldc;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
             const int n = n0 + (wn * NTT + nt) * 32 + r;
             if (n >= g.N) continue;
-            float bias = 0.f, scale = 1.f, sa = 0.f, sib = 0.f, s2a = 0.f, s2ib = 0.f;
-            if (e.split_k == 1) {
-                if (e.bias) bias = e.bias[n];
-                if (e.scale) scale = e.scale[n];
-                if (e.act == ACT_SNAKE) { sa = e.snake_a[n]; sib = e.snake_ib[n]; }
-                if (e.out2_bf16 || e.out2_f32 || e.out2_hi) { s2a = e.snake2_a[n]; s2ib = e.snake2_ib[n]; }
+            const int64_t mb = m0 + (wm * MT + mt) * 32 + 4 * h;       // row of accumulator element 0
+            const int64_t ob = mb * ldc + n;
+            // element i sits (i & 3) + 8 * (i >> 2) rows below
+#define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
+            bool ok[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ok[i] = mb + RT_ROW(i) < M;
+            if (e.split_k > 1) {
+                float* slab = e.out_f32 + (int64_t)blockIdx.z * M * ldc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) slab[ob + RT_ROW(i) * ldc] = acc[mt][nt][i];
+                continue;
             }
-            // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads left
-            // inside the store loop would be serialised behind every earlier store - 64 dependent round trips per thread
+            // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads issued
+            // between the stores would be serialised behind them
             float res[16];
+            if (e.residual) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t m = m0 + (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                res[i] = (e.residual && e.split_k == 1 && m < M) ? e.residual[m * e.ldc + n] : 0.f;
+                for (int i = 0; i < 16; ++i) res[i] = ok[i] ? e.residual[ob + RT_ROW(i) * ldc] : 0.f;
             }
+            const float bias = e.bias ? e.bias[n] : 0.f;
+            float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t m = m0 + (wm * MT + mt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m >= M) continue;
-                float v = acc[mt][nt][i];
-                const int64_t o = m * e.ldc + n;
-                if (e.split_k > 1) { slab[o] = v; continue; }
-                v += bias;
-                if (e.act == ACT_SILU) v = v / (1.f + __expf(-v));
-                else if (e.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                else if (e.act == ACT_SNAKE) { const float s = __sinf(v * sa); v = v + sib * s * s; }
-                else if (e.act == ACT_CLAMP1) v = fminf(1.f, fmaxf(-1.f, v));
-                v *= scale;
-                if (e.residual) v += res[i];
-                if (e.out_f32) e.out_f32[o] = v;
-                if (e.out_bf16) e.out_bf16[o] = f32_to_bf16(v);
-                if (e.out_hi) {
-                    const bf16_t hi = f32_to_bf16(v);
-                    e.out_hi[o] = hi;
-                    e.out_lo[o] = f32_to_bf16(v - bf16_to_f32(hi));
+            for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i] + bias;
+            if (e.act == ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
+            } else if (e.act == ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
+            } else if (e.act == ACT_SNAKE) {
+                const float sa = e.snake_a[n], sib = e.snake_ib[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * sa); v[i] = v[i] + sib * sn * sn; }
+            } else if (e.act == ACT_CLAMP1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fminf(1.f, fmaxf(-1.f, v[i]));
+            }
+            if (e.scale) {
+                const float scale = e.scale[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] *= scale;
+            }
+            if (e.residual) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += res[i];
+            }
+            if (e.out_f32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_f32[ob + RT_ROW(i) * ldc] = v[i];
+            }
+            if (e.out_bf16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+            }
+            if (e.out_hi) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bf16_t hi = f32_to_bf16(v[i]);
+                    const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
+                    if (ok[i]) { e.out_hi[ob + RT_ROW(i) * ldc] = hi; e.out_lo[ob + RT_ROW(i) * ldc] = lo; }
                 }
+            }
+            if (e.out2_hi || e.out2_bf16 || e.out2_f32) {
+                const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
                 if (e.out2_hi) {
-                    const float s = __sinf(v * s2a);
-                    const float v2 = v + s2ib * s * s;
-                    const bf16_t hi = f32_to_bf16(v2);
-                    e.out2_hi[o] = hi;
-                    e.out2_lo[o] = f32_to_bf16(v2 - bf16_to_f32(hi));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bf16_t hi = f32_to_bf16(v[i]);
+                        const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
+                        if (ok[i]) { e.out2_hi[ob + RT_ROW(i) * ldc] = hi; e.out2_lo[ob + RT_ROW(i) * ldc] = lo; }
+                    }
                 }
-                if (e.out2_bf16 || e.out2_f32) {
-                    const float s = __sinf(v * s2a);
-                    const float v2 = v + s2ib * s * s;
-                    if (e.out2_bf16) e.out2_bf16[o] = f32_to_bf16(v2);
-                    if (e.out2_f32) e.out2_f32[o] = v2;
+                if (e.out2_bf16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+                }
+                if (e.out2_f32) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_f32[ob + RT_ROW(i) * ldc] = v[i];
                 }
             }
+#undef RT_ROW
         }
 }
 
