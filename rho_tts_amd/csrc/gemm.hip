@@ -228,7 +228,7 @@ __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B ro
 // 2,2,2,2 = 128 x 128 (default); 4,1,1,3 = 128 x 96 for the codec decoder's 96- and 192-channel stages, where a 128-wide
 // tile would spend a quarter of its MFMAs on padding columns.
 template <bool A_F32, bool SPLIT, int WGM, int WGN, int MT, int NTT>
-__global__ __launch_bounds__(256) void k_gemm_tiled(TiledArgs g) {
+__global__ __launch_bounds__(256, 3) void k_gemm_tiled(TiledArgs g) {
     static_assert(WGM * WGN == 4 && WGM * MT * 32 == BM, "4 waves, 128 rows");
     constexpr int BNT = WGN * NTT * 32;
     constexpr int PLANES = SPLIT ? 2 : 1;
