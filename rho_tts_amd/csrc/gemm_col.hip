@@ -43,12 +43,14 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 // RESID epilogue, or k_rowsq for the first GEMM of a stack) already stored bf16(w_next .* x) in fragment-tiled order, so
 // every GEMM reads a plain bf16 operand with one coalesced load per tile, and the row scale inv_row - from the
 // producer's per-tile sums of squares - is applied to the accumulator in the epilogue (post_scale).
+// The gate/up instantiation is held to 128 VGPRs (shorter chunks) so that two workgroups share a CU: its N/32 workgroups are
+// 1.5x the CUs on the 1.7B talker, and one-per-CU would run them as a full round plus a half-empty one.
 template <int EPI>
-__global__ __launch_bounds__(512) void k_gemm_col(ColArgs g) {
+__global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColArgs g) {
     __shared__ float red[WAVES][2][4][64];   // 16 KiB: two 16x16 accumulator tiles (rows 0-15, 16-31) per wave
     __shared__ float sh_inv[32];             // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int C = (NB == 2) ? 4 : 8;     // k-tiles (32 deep) per super-chunk
+    constexpr int C = (NB == 2) ? 2 : 8;     // k-tiles (32 deep) per super-chunk
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, qd = lane >> 4;
     const int sp_shift = g.split == 4 ? 2 : (g.split == 2 ? 1 : 0);
