@@ -106,6 +106,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 700) { g_col_rows64 = skinny_variant - 700; return RT_OK; }             // 700/701: 32-row / 64-row decode GEMM launches
     if (skinny_variant >= 600) { g_tile96 = skinny_variant - 600; return RT_OK; }                 // 600/601: 128x96 tiles off/on
     if (skinny_variant >= 500) { g_col_split = skinny_variant - 500; return RT_OK; }             // 500: automatic sub-tile split, 501/502/504: forced
     if (skinny_variant >= 400) { g_decode_lanes = skinny_variant - 400; return RT_OK; }          // 40n: n decode lanes
@@ -155,7 +156,7 @@ int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t s
 // Back-to-back launches of the column-owner GEMM over n_mats weight matrices (> 512 MB in total => HBM-cold).
 int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_norm, int32_t epi, int32_t n_mats, int32_t iters,
                       double* avg_us, int64_t* stamps8) {
-    if (!ctx || !avg_us || M < 1 || M > 32 || N < 64 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_col: bad argument");
+    if (!ctx || !avg_us || M < 1 || M > 64 || N < 64 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_col: bad argument");
     std::lock_guard<std::mutex> g(ctx->mu);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pb = packed_bytes(N, K);
@@ -164,16 +165,16 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
     float *out = nullptr, *rowsq = nullptr, *rowsq_out = nullptr, *normw = nullptr;
     bf16_t* act = nullptr;
     RT_HIP(ctx, hipMalloc((void**)&wbuf, pb * n_mats));
-    RT_HIP(ctx, hipMalloc(&a, (size_t)32 * K * 4));
-    RT_HIP(ctx, hipMalloc((void**)&out, (size_t)32 * N * 4));
-    RT_HIP(ctx, hipMalloc((void**)&act, (size_t)32 * N * 2));
-    RT_HIP(ctx, hipMalloc((void**)&rowsq, (size_t)32 * 512 * 4));
-    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)32 * (N / 4 + 4) * 4));
+    RT_HIP(ctx, hipMalloc(&a, (size_t)64 * K * 4));
+    RT_HIP(ctx, hipMalloc((void**)&out, (size_t)64 * N * 4));
+    RT_HIP(ctx, hipMalloc((void**)&act, (size_t)64 * N * 2));
+    RT_HIP(ctx, hipMalloc((void**)&rowsq, (size_t)64 * 512 * 4));
+    RT_HIP(ctx, hipMalloc((void**)&rowsq_out, (size_t)64 * (N / 4 + 4) * 4));
     RT_HIP(ctx, hipMalloc((void**)&normw, (size_t)std::max(K, N) * 4));
     RT_HIP(ctx, hipMemsetAsync(wbuf, 0x3c, pb * n_mats, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(a, 0x3c, (size_t)32 * K * 4, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(out, 0, (size_t)32 * N * 4, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(rowsq, 0x3c, (size_t)32 * 512 * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(a, 0x3c, (size_t)64 * K * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(out, 0, (size_t)64 * N * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(rowsq, 0x3c, (size_t)64 * 512 * 4, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(normw, 0x3c, (size_t)std::max(K, N) * 4, ctx->stream));
     PackedW pw;
     pw.N = N; pw.K = K; pw.Np = (N + 31) / 32 * 32; pw.Kp = K; pw.Np16 = (N + 15) / 16 * 16;

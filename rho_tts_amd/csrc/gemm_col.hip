@@ -45,12 +45,15 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 // producer's per-tile sums of squares - is applied to the accumulator in the epilogue (post_scale).
 // The gate/up instantiation is held to 128 VGPRs (shorter chunks) so that two workgroups share a CU: its N/32 workgroups are
 // 1.5x the CUs on the 1.7B talker, and one-per-CU would run them as a full round plus a half-empty one.
-template <int EPI>
-__global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColArgs g) {
-    __shared__ float red[WAVES][2][4][64];   // 16 KiB: two 16x16 accumulator tiles (rows 0-15, 16-31) per wave
-    __shared__ float sh_inv[32];             // RMSNorm row scales
+// MT = 16-row sub-blocks per launch: 2 (M <= 32, every single-position decode pass) or 4 (M <= 64: the predictor's first
+// pass carries two positions per sequence; one 64-row launch streams the weights once instead of twice).
+template <int EPI, int MT>
+__global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_gemm_col(ColArgs g) {
+    __shared__ float red[WAVES][MT][4][64];  // 16 KiB per 32 rows: one 16x16 accumulator tile per sub-block and wave
+    __shared__ float sh_inv[16 * MT];        // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int C = (NB == 2) ? 2 : 8;     // k-tiles (32 deep) per super-chunk
+    constexpr int C = (NB == 2) ? 2 : (MT == 4 ? 4 : 8);     // k-tiles (32 deep) per super-chunk
+    constexpr int PASSES = MT / 2;           // epilogue / row-scale passes of 32 rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, qd = lane >> 4;
     const int sp_shift = g.split == 4 ? 2 : (g.split == 2 ? 1 : 0);
@@ -63,23 +66,23 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
     if (kt_hi > g.KT) kt_hi = g.KT;
     const int n_k = kt_hi > kt_lo ? kt_hi - kt_lo : 0;
     const int n_sc = (n_k + C - 1) / C;
+    const int n_mt = (g.M + 15) >> 4;                         // sub-blocks that hold rows
 
     const s8_t* wp[NB];
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
     if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
-    // fragment-tiled A, two 16-row sub-blocks: this lane's 8 elements of k-tile kt sit at tile_off(row, 32 kt + 8 qd)
-    const s8_t* ap[2];
+    // fragment-tiled A, 16-row sub-blocks: this lane's 8 elements of k-tile kt sit at tile_off(row, 32 kt + 8 qd)
+    const s8_t* ap[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int row = mt * 16 + r;
         if (row >= g.M) row = g.M - 1;                  // clamp: computed on valid memory, never stored
         ap[mt] = reinterpret_cast<const s8_t*>(reinterpret_cast<const bf16_t*>(g.A) + tile_off(g.row_off + row, kt_lo * 32 + qd * 8, g.K));
     }
-    const bool two = g.M > 16;                          // second sub-block present
 
     struct Chunk {
         s8_t b[NB][C];
-        s8_t a[2][C];
+        s8_t a[MT][C];
     };
     auto issue = [&](int sc, Chunk& ck) {
 #pragma unroll
@@ -91,39 +94,46 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
                 const s8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 ck.b[b][u] = !b_mine ? zero : (g.nt ? __builtin_nontemporal_load(wp[b] + (int64_t)k * 64) : wp[b][(int64_t)k * 64]);
             }
-            ck.a[0][u] = ap[0][(int64_t)k * 64];      // 64 lanes x 16 B = the next contiguous KiB of the sub-block
-            ck.a[1][u] = ap[1][(int64_t)k * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ck.a[mt][u] = ap[mt][(int64_t)k * 64];   // 64 lanes x 16 B = the next contiguous KiB
         }
     };
 
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[0] = wall_clock64();
     Chunk c0, c1;
     if (n_sc > 0) issue(0, c0);
-    // the output element this thread finishes in the epilogue: sub-block mt, accumulator register i, lane l
-    const int e_mt = tid >> 8, e_i = (tid >> 6) & 3, e_l = tid & 63;
-    const int e_row = e_mt * 16 + (e_l >> 4) * 4 + e_i;
+    // the output elements this thread finishes in the epilogue: pass ps -> sub-block 2 ps + (tid >> 8), accumulator register i, lane l
+    const int e_i = (tid >> 6) & 3, e_l = tid & 63;
     const int n = nt * 16 + (e_l & 15);
-    float xres = 0.f;
     const bool e_mine = ((e_l & 15) >> cw_shift) == sub;
-    if (EPI == COL_RESID && e_row < g.M && n < g.N && e_mine) xres = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
-    if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns row 4w + qd, its lanes split the partials
-        const int row_i = 4 * w + qd;
-        const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
-        const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
-        float s = 0.f;
-        for (int j = r; j < g.rowsq_n; j += 16) s += p[j];
+    float xres[PASSES];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
+        xres[ps] = 0.f;
+        if (EPI == COL_RESID && e_row < g.M && n < g.N && e_mine) xres[ps] = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
+    }
+    if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns rows 4w + qd (+ 32 per pass), its lanes split the partials
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row_i = 32 * ps + 4 * w + qd;
+            const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
+            const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
+            float s = 0.f;
+            for (int j = r; j < g.rowsq_n; j += 16) s += p[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
+        }
     }
     if (n_sc > 1) issue(1, c1);
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[1] = wall_clock64();
 
-    f4acc_t acc[NB][2];
+    f4acc_t acc[NB][MT];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[b][mt][i] = 0.f;
 
@@ -132,10 +142,10 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
         for (int u = 0; u < C; ++u) {
             if (sc * C + u < n_k) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    acc[b][0] = mfma16(ck.a[0][u], ck.b[b][u], acc[b][0]);
-                    if (two) acc[b][1] = mfma16(ck.a[1][u], ck.b[b][u], acc[b][1]);
-                }
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (mt == 0 || mt < n_mt) acc[b][mt] = mfma16(ck.a[mt][u], ck.b[b][u], acc[b][mt]);
             }
         }
     };
@@ -150,26 +160,31 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
     }
 
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[3] = wall_clock64();
-    // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue (one output per thread)
-    float val[NB];
+    // ---- combine the 8 K-partials through LDS in a fixed order and run the fused epilogue (one output per thread and pass)
+    float val[NB][PASSES];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         if (b > 0) __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[w][mt][i][lane] = acc[b][mt][i];
         __syncthreads();
-        float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) s += red[ww][e_mt][e_i][e_l];
-        val[b] = s;
+        for (int ps = 0; ps < PASSES; ++ps) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WAVES; ++ww) s += red[ww][2 * ps + (tid >> 8)][e_i][e_l];
+            val[b][ps] = s;
+        }
     }
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[4] = wall_clock64();
-    {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
         const bool ok = e_row < g.M && n < g.N && e_mine;
         const float inv = g.post_scale ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
-        float v = val[0] * inv;
+        float v = val[0][ps] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
                 if (g.bias) v += g.bias[n];
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
             if (ok) {
                 if (g.bias) v += g.bias[n];
                 if (g.scale) v *= g.scale[n];
-                xn = xres + v;
+                xn = xres[ps] + v;
                 const int64_t o = tile_off(g.row_off + e_row, n, (int)g.ldc);
                 g.out[o] = xn;
                 if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(g.next_norm_w[n] * xn);   // operand of the GEMM behind the next RMSNorm
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
             if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + blockIdx.x] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
-                const float u = val[NB - 1] * inv;
+                const float u = val[NB - 1][ps] * inv;
                 g.out_bf16[tile_off(g.row_off + e_row, n, (int)g.ldc)] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
             }
         }
@@ -199,21 +214,19 @@ __global__ __launch_bounds__(512, EPI == COL_SILU ? 4 : 2) void k_gemm_col(ColAr
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
 }
 
+template <int EPI, int MT>
+void launch_one(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
+    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
+    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
+}
+
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
-    if (!e0 && !e1) {   // plain launches are what a stream capture records
-        switch (g.epi) {
-            case COL_STORE: hipLaunchKernelGGL((k_gemm_col<COL_STORE>), grid, dim3(512), 0, ctx->stream, g); break;
-            case COL_RESID: hipLaunchKernelGGL((k_gemm_col<COL_RESID>), grid, dim3(512), 0, ctx->stream, g); break;
-            case COL_SILU: hipLaunchKernelGGL((k_gemm_col<COL_SILU>), grid, dim3(512), 0, ctx->stream, g); break;
-            default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
-        }
-    } else {            // device-side begin/end stamps for the roofline figure
-        switch (g.epi) {
-            case COL_STORE: hipExtLaunchKernelGGL((k_gemm_col<COL_STORE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-            case COL_RESID: hipExtLaunchKernelGGL((k_gemm_col<COL_RESID>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-            case COL_SILU: hipExtLaunchKernelGGL((k_gemm_col<COL_SILU>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g); break;
-            default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
-        }
+    const bool wide = g.M > 32;
+    switch (g.epi) {
+        case COL_STORE: wide ? launch_one<COL_STORE, 4>(ctx, g, grid, e0, e1) : launch_one<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
+        case COL_RESID: wide ? launch_one<COL_RESID, 4>(ctx, g, grid, e0, e1) : launch_one<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
+        case COL_SILU: wide ? launch_one<COL_SILU, 4>(ctx, g, grid, e0, e1) : launch_one<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
+        default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -238,7 +251,7 @@ int col_split_for(int N, int n_cu) {
 }
 
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (a.M < 1 || a.M > 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..32 (callers split larger row blocks)", a.M);
+    if (a.M < 1 || a.M > 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: M=%d outside 1..64 (callers split larger row blocks)", a.M);
     if (w.K != a.K || w.K % 32) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: K mismatch (%d vs %d) or not a multiple of 32", w.K, a.K);
     if (!w.data16) return rt_fail(ctx, RT_ERR_STATE, "gemm_col: weight has no 16-column decode copy");
     ColArgs g = a;

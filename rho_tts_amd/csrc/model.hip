@@ -380,12 +380,13 @@ int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w) {
     RT_TRY(pool_arr(m, Mp * d.inter, &w->act));
     return RT_OK;
 }
-// Row blocks of 32: a 64-row pass (the predictor's first, 2 rows per sequence) streams the weights twice.
+// Row blocks of up to 64 (one launch for the predictor's two-position first pass at batch 32).
 int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor = false) {
-    for (int r0 = 0; r0 < a0.M; r0 += 32) {
+    const int blk = g_col_rows64 ? 64 : 32;
+    for (int r0 = 0; r0 < a0.M; r0 += blk) {
         ColArgs a = a0;
         a.nt = is_predictor ? g_pred_nt : 1;
-        a.M = std::min(32, a0.M - r0);
+        a.M = std::min(blk, a0.M - r0);
         a.row_off = a0.row_off + r0;
         hipEvent_t e0, e1;
         prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);

@@ -227,3 +227,40 @@ def test_decode_lanes_and_tile_split_do_not_change_results(ctx):
                 assert float((a - b).abs().max()) <= 1e-3 * float(a.std()) + 1e-6
     finally:
         nm.close()
+
+
+def test_64_row_decode_launches_match_32_row_launches(ctx):
+    """Batches of 17..32 sequences put 2B > 32 rows into the predictor's first pass: one 64-row column-GEMM launch
+    (rt_debug_tune 701, default) must give bit-identical logits to two 32-row launches (700), and both stay within the
+    legacy path's tolerance."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg = config.PRESETS["tiny"]()
+    nm, _ = build(ctx, cfg, max_batch=24)
+    try:
+        set_voice(nm, make_voice(cfg, True))
+        g = torch.Generator().manual_seed(5)
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(n),), generator=g)] for n in torch.randint(1, 9, (21,), generator=g)]
+        frames = [int(v) for v in torch.randint(3, 7, (21,), generator=g)]
+        lib = nm.lib
+        sp = RtSampling(1, 0.9, 50, 1.0, 1.05)
+        codes64, tr64 = nm.generate(texts, frames, sp, seed=99, trace=True)
+        try:
+            lib.rt_debug_tune(700, 0)
+            codes32, tr32 = nm.generate(texts, frames, sp, seed=99, trace=True)
+            lib.rt_debug_tune(100, 0)
+            _, tr_legacy = nm.generate(texts, frames, RtSampling(0, 1, 1, 1, 1), forced_codes=codes64, trace=True)
+        finally:
+            lib.rt_debug_tune(701, 0)
+            lib.rt_debug_tune(101, 0)
+        assert all(torch.equal(a, b) for a, b in zip(codes64, codes32))
+        for key in ("talker", "predictor"):
+            assert torch.equal(tr64[key], tr32[key])
+        _, tr_forced = nm.generate(texts, frames, RtSampling(0, 1, 1, 1, 1), forced_codes=codes64, trace=True)
+        V0 = cfg.codec.codebook_size
+        for key in ("talker", "predictor"):
+            a, b = tr_legacy[key].cpu(), tr_forced[key].cpu()
+            if key == "talker":
+                a, b = a[..., :V0], b[..., :V0]
+            assert float((a - b).abs().max()) <= 0.06 * float(a.std()) + 1e-6
+    finally:
+        nm.close()
