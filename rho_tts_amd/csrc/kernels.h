@@ -77,6 +77,7 @@ extern int g_use_graph;
 extern int g_pred_nt;
 extern int g_decode_lanes;
 extern int g_tile96;
+extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
 extern int g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
 extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
 int col_split_for(int N, int n_cu);
@@ -207,6 +208,15 @@ struct SampleArgs {
     int64_t out_fs, eos_fs, forced_fs, copy_fs;
     int eos_live, min_frames;
     long long* stamps;         // debug: wall-clock (100 MHz) stamps of row 0 at the phase boundaries, or null
+    // optional fused next-step input (k_sample_w only): the drawn token's row of emb_table [V][emb_H] (f32) becomes the next
+    // pass's input - tiled x, tiled bf16(emb_norm_w .* x) and the rowsq seed - without a separate gather launch
+    const float* emb_table;
+    int emb_H;
+    const float* emb_norm_w;
+    float* emb_rowsq;
+    int emb_rowsq_n;
+    float* emb_x_tiled;
+    bf16_t* emb_a_tiled;
 };
 int launch_sample(rt_ctx* ctx, const SampleArgs& a);
 

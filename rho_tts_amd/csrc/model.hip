@@ -1008,9 +1008,15 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + ((size_t)q * B + ln.b0) * Vp : nullptr;
             sp.copy_fs = (int64_t)(G - 1) * B * Vp;
             sp.frame_ptr = ln.d_frame; sp.eos_live = 0; sp.min_frames = 0;
+            const bool fuse_emb = col && g_fuse_sample_embed && q < G - 2 && Vp <= 4096 && Hp % 8 == 0;
+            if (fuse_emb) {     // the sampler itself turns the drawn code into the next pass's input
+                sp.emb_table = m->proj_emb[q]; sp.emb_H = Hp; sp.emb_norm_w = m->pred.L[0].ln1; sp.emb_rowsq = ln.rowsq_p; sp.emb_rowsq_n = NTp;
+                sp.emb_x_tiled = ln.dwp.xT; sp.emb_a_tiled = ln.dwp.xa;
+            }
             RT_TRY(launch_sample(ctx, sp));
             if (q < G - 2) {
-                if (col) {      // (col implies has_mtp)
+                if (fuse_emb) {
+                } else if (col) {      // (col implies has_mtp)
                     RT_TRY(launch_embed_rowsq(ctx, nullptr, 0, m->proj_emb[q], codes + q + 1, G, ln.d_frame, codes_fs, n, Hp, nullptr, ln.rowsq_p,
                                               NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
                 } else if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
 // select made of 64-lane ballots (no LDS histograms, no atomics), each of the 4 waves keeps its own top-k, wave 0
 // selects the final k out of those 4k with unique 64-bit (value, index) keys, sorts them with the one-wave bitonic
 // network and walks the ordered CDF exactly as oracle/sampling.py defines it.
+typedef __attribute__((ext_vector_type(4))) float f4s_t;
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -452,6 +453,39 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
         if (A.eos_token >= 0 && token == A.eos_token) { is_eos = 1; token = 0; }
         if (A.eos_flag) A.eos_flag[row] = is_eos;
         A.out[(int64_t)row * A.out_stride] = token;
+        sh_i[0] = token;
+    }
+    if (A.emb_table) {      // next pass's input straight from the drawn token (same arithmetic as k_embed_rowsq's f32-table mode)
+        __syncthreads();
+        const int tok = sh_i[0];
+        const int H = A.emb_H;
+        float ss = 0.f;
+        for (int c = tid * 8; c < H; c += 2048) {
+            float e[8];
+            const f4s_t a = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c);
+            const f4s_t b = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { e[q] = 0.f + a[q]; e[4 + q] = 0.f + b[q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ss += e[q] * e[q];
+            const int64_t o = tile_off(row, c, H);
+            *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o) = f4s_t{e[0], e[1], e[2], e[3]};
+            *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o + 4) = f4s_t{e[4], e[5], e[6], e[7]};
+            const f4s_t w0 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c), w1 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c + 4);
+            uint4 pk;
+            pk.x = f32x2_to_bf16x2(w0[0] * e[0], w0[1] * e[1]);
+            pk.y = f32x2_to_bf16x2(w0[2] * e[2], w0[3] * e[3]);
+            pk.z = f32x2_to_bf16x2(w1[0] * e[4], w1[1] * e[5]);
+            pk.w = f32x2_to_bf16x2(w1[2] * e[6], w1[3] * e[7]);
+            *reinterpret_cast<uint4*>(A.emb_a_tiled + o) = pk;
+        }
+        // block sum in the order k_embed_rowsq uses (wave sums, then waves 0..3)
+        ss = wave_sum_f32(ss);
+        __syncthreads();
+        if (lane == 0) sh_f[w] = ss;
+        __syncthreads();
+        const float tot = ((sh_f[0] + sh_f[1]) + sh_f[2]) + sh_f[3];
+        for (int j = tid; j < A.emb_rowsq_n; j += 256) A.emb_rowsq[(int64_t)row * A.emb_rowsq_n + j] = j == 0 ? tot : 0.f;
     }
 }
 
@@ -462,6 +496,8 @@ int launch_sample(rt_ctx* ctx, const SampleArgs& a) {
     if (a.do_sample && (a.top_k < 1 || a.top_k > 64)) return rt_fail(ctx, RT_ERR_INVALID, "sampling needs 1 <= top_k <= 64 (got %d)", a.top_k);
     if (a.do_sample && !(a.temperature > 0.f)) return rt_fail(ctx, RT_ERR_INVALID, "sampling needs temperature > 0");
     if (a.V > 16384) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "vocabulary %d too large for the sampler", a.V);
+    if (a.emb_table && (a.V > 4096 || a.emb_H % 8 || !a.emb_norm_w || !a.emb_rowsq || a.emb_rowsq_n < 1 || !a.emb_x_tiled || !a.emb_a_tiled))
+        return rt_fail(ctx, RT_ERR_INVALID, "sample: fused embedding needs V <= 4096, H %% 8 == 0 and all its buffers");
     if (a.V <= 1024) hipLaunchKernelGGL(k_sample_w<4>, dim3(a.M), dim3(256), 0, ctx->stream, a);
     else if (a.V <= 2048) hipLaunchKernelGGL(k_sample_w<8>, dim3(a.M), dim3(256), 0, ctx->stream, a);
     else if (a.V <= 4096) hipLaunchKernelGGL(k_sample_w<16>, dim3(a.M), dim3(256), 0, ctx->stream, a);

@@ -211,6 +211,14 @@ def test_decode_lanes_and_tile_split_do_not_change_results(ctx):
         assert all(torch.equal(a, b) for a, b in zip(base, two))
         for key in ("talker", "predictor"):
             assert torch.equal(tr0[key], tr2[key])
+        try:        # sampler with the next-input embedding fused in (801, default) == separate gather launch (800)
+            lib.rt_debug_tune(800, 0)
+            sep, tr_sep = nm.generate(texts, frames, sp, seed=77, trace=True)
+        finally:
+            lib.rt_debug_tune(801, 0)
+        assert all(torch.equal(a, b) for a, b in zip(base, sep))
+        for key in ("talker", "predictor"):
+            assert torch.equal(tr0[key], tr_sep[key])
         outs = {}
         try:
             for code in (501, 502, 504):
