@@ -517,6 +517,7 @@ int g_pred_nt = 0;              // predictor weights: 0 = cacheable loads (Infin
 int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
 int g_col_rows64 = 1;           // 1: one 64-row decode GEMM launch for the predictor's two-position pass, 0: two 32-row launches
 int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
+int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)

@@ -303,7 +303,8 @@ int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* s
         // prefill: a few hundred rows give only a handful of 128x128 tiles; split K until the grid covers the chip
         const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);
         int S = 1;
-        while (S < 8 && tiles * S < m->ctx->n_cu && W.K / (S * 2) >= 256) S *= 2;
+        // (each workgroup's K loop is a chain of ~1-us load round trips, so the grid should be ~3 workgroups per CU deep)
+        while (S < 8 && tiles * S < g_prefill_fill * m->ctx->n_cu && W.K / (S * 2) >= 256) S *= 2;
         GemmA a; a.ptr = A; a.is_f32 = 0; a.M = rows; a.Cin = W.K; a.taps = 1;
         GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = S;
         RT_TRY(launch_gemm(m->ctx, a, W, e));

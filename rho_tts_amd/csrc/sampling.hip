@@ -403,20 +403,25 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
             if (n > 0) {
                 const float mx = lane_f32(c.v, 0);
                 const float p = lane < n ? expf(__fsub_rn(c.v, mx)) : 0.f;
-                float tot = 0.f;
-                for (int j = 0; j < n; ++j) tot = __fadd_rn(tot, lane_f32(p, j));
+                // ONE sequential pass builds the ordered running sums (cum_j lands on lane j): the total, the top-p cut and
+                // the inverse-CDF pick are then ballots over them - the same additions in the same order as the oracle's
+                // three loops, each done once
+                float cum = 0.f, mycum = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    cum = __fadd_rn(cum, lane_f32(p, j));
+                    if (lane == j) mycum = cum;
+                }
+                float tot = cum;
                 int keep = n;
                 if (A.top_p < 1.0f) {
                     const float lim = __fmul_rn(A.top_p, tot);
-                    float cum = 0.f;
-                    for (int j = 0; j < n; ++j) { cum = __fadd_rn(cum, lane_f32(p, j)); if (cum >= lim) { keep = j + 1; break; } }
-                    tot = cum;
+                    const unsigned long long reach = __ballot(lane < n && mycum >= lim);
+                    if (reach) { keep = __builtin_ctzll(reach) + 1; tot = lane_f32(mycum, keep - 1); }
                 }
                 const float u = rt_uniform(A.seed, (unsigned)A.item_ids[row], (unsigned)A.frame, (unsigned)A.group);
                 const float target = __fmul_rn(u, tot);
-                float cum = 0.f;
-                int pick_lane = keep - 1;
-                for (int j = 0; j < keep; ++j) { cum = __fadd_rn(cum, lane_f32(p, j)); if (cum > target) { pick_lane = j; break; } }
+                const unsigned long long over = __ballot(lane < keep && mycum > target);
+                const int pick_lane = over ? __builtin_ctzll(over) : keep - 1;
                 token = lane_i32(c.idx, pick_lane);
             }
             if (lane == 0) sh_i[0] = n > 0 ? 0 : 1;      // no finite candidate at all: fall back to the arg-max rule

@@ -10,6 +10,8 @@ from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
 
 cfg = config.PRESETS["1.7b"]()
 eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32)
+for code in sys.argv[1:]:
+    eng.ctx.lib.rt_debug_tune(int(code), 0)
 texts = bench.sentences(32, 10, seed=789)
 clip = synthetic_reference_clip(30.0, cfg.sample_rate, 789)
 ref_text = " ".join(bench.WORDS[i % len(bench.WORDS)] for i in range(75))
