@@ -37,6 +37,32 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
     const int slot = row_slot[row];
     const float scale = rsqrtf((float)D);
+    const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
+    const bf16_t* kb = kc + base * D + sub * 8;
+    const bf16_t* vb = vc + base * D + sub * 8;
+    // rows below prefix_len come from the shared prefix slot (same bytes for every sequence -> cache hits)
+    const int64_t pdelta = prefix_slot >= 0 ? (((int64_t)prefix_slot - slot) * kv_heads * max_pos) * D : 0;
+    constexpr int STEP = NW * PPW;    // positions the workgroup covers per load slot
+    u4_t kk[U], vv[U];
+    auto load_batch = [&](int p0, int last) {      // positions p0 + u * STEP, clamped to [0, last]
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * STEP;
+            int pc = p <= last ? p : last;
+            if (pc < 0) pc = 0;
+            const int64_t po = (int64_t)pc * D + (pc < prefix_len ? pdelta : 0);
+            kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
+            vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
+        }
+    };
+    const int p_first = lo + w * PPW + pg;
+    // The cached positions of the first batch are requested BEFORE the q/k/v prologue, so their round trip overlaps the
+    // prologue's own loads and reductions.  The row this launch appends (position hi) - and any position sharing a 128-B
+    // line with it, which would sit stale in L1 - is left out and read after the barrier.
+    constexpr int RPL = (D * 2 >= 128) ? 1 : 128 / (D * 2);
+    const int pre_last = (hi / RPL) * RPL - 1;
+    constexpr bool PRE = FUSED && REP <= 2;       // (4 query heads per kv head leave no registers for the early batch)
+    if (PRE) load_batch(p_first, pre_last);
 
     if (FUSED) {
         // vectors of this head group: REP query heads, then K, then V; wave w takes vectors w, w+4, ...
@@ -90,21 +116,19 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[r][j] = 0.f;
     }
-    const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
-    const bf16_t* kb = kc + base * D + sub * 8;
-    const bf16_t* vb = vc + base * D + sub * 8;
-    // rows below prefix_len come from the shared prefix slot (same bytes for every sequence -> cache hits)
-    const int64_t pdelta = prefix_slot >= 0 ? (((int64_t)prefix_slot - slot) * kv_heads * max_pos) * D : 0;
-
-    for (int p0 = lo + w * PPW + pg; p0 <= hi; p0 += NW * PPW * U) {
-        u4_t kk[U], vv[U];
+    for (int p0 = p_first; p0 <= hi; p0 += STEP * U) {
+        if (PRE && p0 == p_first) {        // first batch: already in flight, patch the positions the prefetch had to skip
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int p = p0 + u * NW * PPW;
-            const int pc = p <= hi ? p : hi;
-            const int64_t po = (int64_t)pc * D + (pc < prefix_len ? pdelta : 0);
-            kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
-            vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * STEP;
+                if (p > pre_last && p <= hi) {
+                    const int64_t po = (int64_t)p * D + (p < prefix_len ? pdelta : 0);
+                    kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
+                    vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
+                }
+            }
+        } else {
+            load_batch(p0, hi);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
