@@ -222,11 +222,10 @@ struct SampleArgs {
 int launch_sample(rt_ctx* ctx, const SampleArgs& a);
 
 // -------------------------------------------------------------------------------- codec elementwise
-int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* a, const float* ib, bf16_t* out_bf16);
+
 int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w /*[7][C]*/, const float* b,
                      const float* ln_w, const float* ln_b, float eps, float* out_f32);
 int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q, int H, const int32_t* codes /*[B][T][Q]*/,
                            int64_t rows, float* out_f32);
-int launch_final_conv(rt_ctx* ctx, const float* x_snaked, int B, int T, int C, const float* w /*[7][C]*/, float bias,
-                      float* wav /*[B][T]*/);
+
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out);

@@ -45,20 +45,6 @@ struct PoolBlock { void* p; size_t size; bool used; };
 __global__ void k_bf16_to_f32(const bf16_t* __restrict__ x, int64_t n, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = bf16_to_f32(x[i]);
 }
-// prefix KV (slot `src`) -> every slot in [0, n_dst): one workgroup per (layer*kv_head, dst slot)
-__global__ void k_kv_fanout(bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int64_t layer_stride, int kv_heads, int max_pos, int d,
-                            int src, int prefix_len) {
-    const int lh = blockIdx.x, dst = blockIdx.y;
-    const int layer = lh / kv_heads, kh = lh % kv_heads;
-    const int64_t so = layer * layer_stride + ((int64_t)src * kv_heads + kh) * max_pos * d;
-    const int64_t dof = layer * layer_stride + ((int64_t)dst * kv_heads + kh) * max_pos * d;
-    const int64_t n16 = (int64_t)prefix_len * d / 8;
-    const uint4* ks = reinterpret_cast<const uint4*>(kc + so);
-    const uint4* vs = reinterpret_cast<const uint4*>(vc + so);
-    uint4* kd = reinterpret_cast<uint4*>(kc + dof);
-    uint4* vd = reinterpret_cast<uint4*>(vc + dof);
-    for (int64_t i = threadIdx.x; i < n16; i += blockDim.x) { kd[i] = ks[i]; vd[i] = vs[i]; }
-}
 // blob [2][layers][kv_heads][prefix_len][d] <-> cache slot
 __global__ void k_kv_blob(bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int64_t layer_stride, int layers, int kv_heads, int max_pos,
                           int d, int slot, int prefix_len, bf16_t* __restrict__ blob, int to_blob) {

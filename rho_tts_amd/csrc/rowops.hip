@@ -284,16 +284,6 @@ __global__ __launch_bounds__(256) void k_gather_f32(const float* __restrict__ ta
     }
 }
 
-// ----------------------------------------------------------------------------- codec elementwise
-__global__ void k_snake(const float* __restrict__ x, int64_t total, int C, const float* __restrict__ a, const float* __restrict__ ib,
-                        bf16_t* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const float v = x[i];
-        const float s = __sinf(v * a[c]);
-        out[i] = f32_to_bf16(v + ib[c] * s * s);
-    }
-}
 
 // ConvNeXt front half: depthwise causal conv k=7 over time, then LayerNorm over channels -> bf16.
 // One workgroup per (b, t) row; channels-last so the 7 taps are 7 contiguous rows.
@@ -338,26 +328,6 @@ __global__ __launch_bounds__(256) void k_code_embed_mean(const bf16_t* __restric
     }
 }
 
-// Last conv of the decoder: C channels -> 1, k = 7, causal, then clamp(-1, 1).  One wave per output sample
-// would waste lanes at C = 96; instead each thread owns one sample and walks 7*C contiguous bf16.
-__global__ __launch_bounds__(256) void k_final_conv(const float* __restrict__ x, int T, int C, const float* __restrict__ w, float bias,
-                                                    float* __restrict__ wav, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i % T);
-        float acc = bias;
-        for (int k = 0; k < 7; ++k) {
-            const int tt = t - 6 + k;
-            if (tt < 0) continue;
-            const float* p = x + (i - 6 + k) * C;
-            const float* wk = w + k * C;
-            for (int c = 0; c < C; c += 4) {
-                const f4_t v = *reinterpret_cast<const f4_t*>(p + c);
-                acc += v[0] * wk[c] + v[1] * wk[c + 1] + v[2] * wk[c + 2] + v[3] * wk[c + 3];
-            }
-        }
-        wav[i] = fminf(1.f, fmaxf(-1.f, acc));
-    }
-}
 
 __global__ void k_f32_to_bf16(const float* __restrict__ x, int64_t n, bf16_t* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -454,13 +424,6 @@ int launch_gather_f32(rt_ctx* ctx, const float* table, int H, const int32_t* d_i
     return RT_OK;
 }
 
-int launch_snake(rt_ctx* ctx, const float* x, int64_t rows, int C, const float* a, const float* ib, bf16_t* out_bf16) {
-    const int64_t total = rows * C;
-    if (total <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_snake, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x, total, C, a, ib, out_bf16);
-    RT_HIP(ctx, hipGetLastError());
-    return RT_OK;
-}
 
 int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const float* w, const float* b, const float* ln_w,
                      const float* ln_b, float eps, float* out_f32) {
@@ -478,14 +441,6 @@ int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q
     return RT_OK;
 }
 
-int launch_final_conv(rt_ctx* ctx, const float* x_snaked, int B, int T, int C, const float* w, float bias, float* wav) {
-    const int64_t total = (int64_t)B * T;
-    if (total <= 0) return RT_OK;
-    if (C % 8) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "final conv: channels %d not a multiple of 8", C);
-    hipLaunchKernelGGL(k_final_conv, dim3(grid_for(total)), dim3(256), 0, ctx->stream, x_snaked, T, C, w, bias, wav, total);
-    RT_HIP(ctx, hipGetLastError());
-    return RT_OK;
-}
 
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out) {
     if (n <= 0) return RT_OK;
