@@ -215,6 +215,7 @@ struct TiledArgs {
     int N, K, NT, KT;
     GemmEpi e;
     int kt_per_split;  // in 16-wide k tiles, multiple of 2
+    int xcd_order = 0;   // 1: XCD-aware tile order (see k_gemm_tiled)
 };
 
 __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B rows, 16-B slots XOR-swizzled by row/4
@@ -237,8 +238,22 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tiled(TiledArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WGN, wn = w % WGN;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;   // x: row tiles (can exceed 65535), y: column tiles
-    const int n0 = blockIdx.y * BNT;
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs in launch order, each XCD with its own 4-MiB L2.  With
+    // g.xcd_order the launch index is re-read so that ONE XCD runs all the column tiles of a row tile back to back: the A
+    // rows (7 taps x n column tiles of re-reads in the codec decoder) are then fetched into that L2 once instead of once per
+    // column tile (the 768-channel stage missed L2 on half of 68 M requests per launch with the plain x-fastest order).
+    int64_t rt = blockIdx.x;                       // x: row tiles (can exceed 65535), y: column tiles
+    int ct = blockIdx.y;
+    if (g.xcd_order) {
+        const int64_t L = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;      // gridDim.x is a multiple of 8 here
+        const int xcd = (int)(L & 7);
+        const int64_t j = L >> 3;
+        ct = (int)(j % gridDim.y);
+        rt = (j / gridDim.y) * 8 + xcd;
+        if (rt * BM >= g.a.M) return;              // padding tiles of the rounded-up row count
+    }
+    const int64_t m0 = rt * BM;
+    const int n0 = ct * BNT;
     const int kt0 = blockIdx.z * g.kt_per_split;
     int kt1 = kt0 + g.kt_per_split;
     if (kt1 > g.KT) kt1 = g.KT;
@@ -518,6 +533,7 @@ int g_use_graph = 1;            // 1: the decode frame is replayed from captured
 int g_col_rows64 = 1;           // 1: one 64-row decode GEMM launch for the predictor's two-position pass, 0: two 32-row launches
 int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
 int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
+int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
@@ -587,7 +603,9 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     // 96-wide workgroup tiles when N is a multiple of 96 but not of 128 (the decoder's 96- and 192-channel stages)
     const bool narrow = g_tile96 && e.split_k == 1 && w.N % 96 == 0 && w.N % 128 != 0;
     const int bn = narrow ? 96 : BN;
-    dim3 grid((unsigned)my, (w.N + bn - 1) / bn, e.split_k);
+    const int ny = (w.N + bn - 1) / bn;
+    g.xcd_order = (g_xcd_order && e.split_k == 1 && ny > 1 && my >= 64) ? 1 : 0;
+    dim3 grid((unsigned)(g.xcd_order ? (my + 7) / 8 * 8 : my), ny, e.split_k);
     if (a.split && !a.is_f32 && !a.ptr_lo) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand or a low plane");
     if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || !e.snake2_a || !e.snake2_ib)) || ((e.out_hi || e.out2_hi) && e.split_k > 1))
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");

@@ -77,6 +77,7 @@ extern int g_use_graph;
 extern int g_pred_nt;
 extern int g_decode_lanes;
 extern int g_tile96;
+extern int g_xcd_order;
 extern int g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
 extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
 extern int g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
