@@ -129,6 +129,10 @@ int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const fl
                        const int32_t* frame_ptr, int64_t idx_frame_stride, int M, int H, const float* add_vec, float* rowsq, int rowsq_n,
                        float* x_tiled, bf16_t* a_tiled, const float* norm_w);
 
+// out[M][H] (row-major f32) = norm_w .* x * inv_rms(row) from the column path's tiled x and its rowsq partials
+int launch_norm_tiled_rows(rt_ctx* ctx, const float* x_tiled, const float* rowsq, int rowsq_n, const float* w, float eps, int M, int H,
+                           float* out);
+
 // ---------------------------------------------------------------------------------- row kernels
 // x[M][H] (f32, updated in place when n_slabs > 0 or add != nullptr):
 //   x += scale[:] * sum_s slab[s]   (slab stride M*H; scale may be null)

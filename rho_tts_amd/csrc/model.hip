@@ -858,8 +858,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     RT_HIP(ctx, hipMemcpyAsync(d_seed, &A->seed, 8, hipMemcpyHostToDevice, ctx->stream));
     const int64_t codes_fs = (int64_t)B * G;
     // Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
-    const bool col = g_decode_col && 2 * B <= 64 && m->has_mtp() && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 &&
-                     c.predictor.inter % 32 == 0;   // (equal-width predictor: the legacy path materialises the past hidden)
+    const bool col = g_decode_col && 2 * B <= 64 && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 && c.predictor.inter % 32 == 0;
     const int NTt = H / 16 * col_split_for(H, ctx->n_cu), NTp = Hp / 16 * col_split_for(Hp, ctx->n_cu);   // rowsq partials per row
     const PackedW& head = PW(m, "talker.codec_head");
     float* x_all = x;
@@ -967,7 +966,9 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             }
             RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, codes, n, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
         } else {
-            RT_HIP(ctx, hipMemcpyAsync(ln.xp, ln.hn_f32, (size_t)n * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            // equal-width predictor: its first input row is the talker's normalised hidden state itself
+            if (col) RT_TRY(launch_norm_tiled_rows(ctx, ln.dwt.xT, ln.rowsq_t, NTt, m->talker.norm, c.talker.rms_eps, n, H, ln.xp));
+            else RT_HIP(ctx, hipMemcpyAsync(ln.xp, ln.hn_f32, (size_t)n * H * 4, hipMemcpyDeviceToDevice, ctx->stream));
             RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, 1, codes, n, H, nullptr, nullptr, nullptr, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
         }
         if (col) {
@@ -995,7 +996,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + ((size_t)q * B + ln.b0) * Vp : nullptr;
             sp.copy_fs = (int64_t)(G - 1) * B * Vp;
             sp.frame_ptr = ln.d_frame; sp.eos_live = 0; sp.min_frames = 0;
-            const bool fuse_emb = col && g_fuse_sample_embed && q < G - 2 && Vp <= 4096 && Hp % 8 == 0;
+            const bool fuse_emb = col && m->has_mtp() && g_fuse_sample_embed && q < G - 2 && Vp <= 4096 && Hp % 8 == 0;
             if (fuse_emb) {     // the sampler itself turns the drawn code into the next pass's input
                 sp.emb_table = m->proj_emb[q]; sp.emb_H = Hp; sp.emb_norm_w = m->pred.L[0].ln1; sp.emb_rowsq = ln.rowsq_p; sp.emb_rowsq_n = NTp;
                 sp.emb_x_tiled = ln.dwp.xT; sp.emb_a_tiled = ln.dwp.xa;
@@ -1003,9 +1004,12 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             RT_TRY(launch_sample(ctx, sp));
             if (q < G - 2) {
                 if (fuse_emb) {
-                } else if (col) {      // (col implies has_mtp)
+                } else if (col && m->has_mtp()) {
                     RT_TRY(launch_embed_rowsq(ctx, nullptr, 0, m->proj_emb[q], codes + q + 1, G, ln.d_frame, codes_fs, n, Hp, nullptr, ln.rowsq_p,
                                               NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
+                } else if (col) {      // equal-width predictor: the group's own bf16 embedding table
+                    RT_TRY(launch_embed_rowsq(ctx, m->d_frame_srcs + q + 1, 1, nullptr, codes + q + 1, G, ln.d_frame, codes_fs, n, Hp, nullptr,
+                                              ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
                 } else if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));
                 else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, codes + q + 1, n, H, nullptr, nullptr, nullptr, ln.xp, nullptr, G, ln.d_frame, codes_fs));
                 if (col) {

@@ -164,6 +164,22 @@ __global__ __launch_bounds__(256) void k_embed_rowsq(const GatherSrc* __restrict
     for (int j = tid; j < rowsq_n; j += 256) rowsq[(int64_t)row * rowsq_n + j] = j == 0 ? tot : 0.f;
 }
 
+// rmsnorm of the column path's tiled residual stream back to plain rows: out[row][c] = w[c] * x[row][c] * rsqrt(sum(rowsq[row]) / H
+// + eps).  Only an equal-width predictor needs it (its first input row is the talker's normalised hidden state itself).
+__global__ __launch_bounds__(256) void k_norm_tiled_rows(const float* __restrict__ x_tiled, const float* __restrict__ rowsq, int rowsq_n,
+                                                         const float* __restrict__ w, float eps, int H, float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < rowsq_n; j += 256) s += rowsq[(int64_t)row * rowsq_n + j];
+    const float inv = rsqrtf(block_sum_f32(s, sh) / (float)H + eps);
+    for (int c = threadIdx.x * 4; c < H; c += 1024) {
+        const f4_t v = *reinterpret_cast<const f4_t*>(x_tiled + tile_off(row, c, H));
+        const f4_t wv = *reinterpret_cast<const f4_t*>(w + c);
+        *reinterpret_cast<f4_t*>(out + (int64_t)row * H + c) = f4_t{wv[0] * (v[0] * inv), wv[1] * (v[1] * inv), wv[2] * (v[2] * inv), wv[3] * (v[3] * inv)};
+    }
+}
+
 __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
                            int64_t total4) {
     const int I4 = I >> 2;
@@ -369,6 +385,15 @@ int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const fl
         return rt_fail(ctx, RT_ERR_INVALID, "embed_rowsq: n_src %d (<= 16), H %d (multiple of 8) or a missing buffer", n_src, H);
     hipLaunchKernelGGL(k_embed_rowsq, dim3(M), dim3(256), 0, ctx->stream, d_srcs, n_src, f32_table, d_idx, idx_stride, frame_ptr,
                        idx_frame_stride, H, add_vec, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_norm_tiled_rows(rt_ctx* ctx, const float* x_tiled, const float* rowsq, int rowsq_n, const float* w, float eps, int M, int H,
+                           float* out) {
+    if (M <= 0) return RT_OK;
+    if (H % 8) return rt_fail(ctx, RT_ERR_INVALID, "norm_tiled_rows: H %d not a multiple of 8", H);
+    hipLaunchKernelGGL(k_norm_tiled_rows, dim3(M), dim3(256), 0, ctx->stream, x_tiled, rowsq, rowsq_n, w, eps, H, out);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -272,3 +272,44 @@ def test_64_row_decode_launches_match_32_row_launches(ctx):
             assert float((a - b).abs().max()) <= 0.06 * float(a.std()) + 1e-6
     finally:
         nm.close()
+
+
+def test_equal_width_predictor_takes_the_column_path_too(ctx):
+    """0.6B-style model: predictor hidden == talker hidden, no mtp projection; the predictor's first input row is the talker's
+    normalised hidden state itself.  Teacher-forced logits of the column path match the oracle (4 % of sigma) and the legacy path."""
+    import dataclasses
+    from rho_tts_amd._native_model import RtSampling
+    base = config.PRESETS["tiny"]()
+    cfg = dataclasses.replace(base, name="tiny-equal", predictor=dataclasses.replace(base.predictor, hidden=base.talker.hidden))
+    assert not cfg.has_mtp_proj
+    nm, om = build(ctx, cfg)
+    try:
+        v = make_voice(cfg, True)
+        set_voice(nm, v)
+        tr_o = {}
+        free = om.generate(v, TEXTS, FRAMES, SamplingParams(), trace=tr_o)
+        _, tr = nm.generate(TEXTS, FRAMES, RtSampling(0, 1.0, 1, 1.0, 1.0), forced_codes=free, trace=True)
+        try:
+            nm.lib.rt_debug_tune(100, 0)
+            _, tr_legacy = nm.generate(TEXTS, FRAMES, RtSampling(0, 1.0, 1, 1.0, 1.0), forced_codes=free, trace=True)
+        finally:
+            nm.lib.rt_debug_tune(101, 0)
+        T = len(tr_o["talker_logits"])
+        valid = torch.zeros(T, len(TEXTS), dtype=torch.bool)
+        for b, n in enumerate(FRAMES):
+            valid[:n, b] = True
+        V0 = cfg.codec.codebook_size
+        t_o = torch.stack(tr_o["talker_logits"])
+        err = (tr["talker"][:T].cpu() - t_o)[valid][:, :V0].abs().max()
+        assert float(err) <= 0.04 * float(t_o[valid][:, :V0].std()), float(err)
+        p_o = torch.stack(tr_o["pred_logits"]).view(T, cfg.n_groups - 1, len(TEXTS), -1)
+        vp = valid[:, None, :].expand(-1, cfg.n_groups - 1, -1)
+        err = (tr["predictor"][:T].cpu() - p_o)[vp].abs().max()
+        assert float(err) <= 0.04 * float(p_o[vp].std()), float(err)
+        for key in ("talker", "predictor"):
+            a, b = tr_legacy[key].cpu(), tr[key].cpu()
+            if key == "talker":
+                a, b = a[..., :V0], b[..., :V0]
+            assert float((a - b).abs().max()) <= 0.06 * float(a.std()) + 1e-6
+    finally:
+        nm.close()
