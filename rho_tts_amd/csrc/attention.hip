@@ -26,6 +26,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     constexpr int U = 4;              // positions in flight per lane
     __shared__ float sh[NW][REP][LPP][10];     // NW waves split the cached positions of one (row, kv head)
     __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
+    __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][FUSED ? D : 8];   // the appended K / V row (as rounded for the cache)
 
     // x = kv head (fastest): workgroups are dealt round-robin over the 8 XCDs, so with 8 kv heads every XCD's L2 holds
     // ONE head's shared-prefix K/V and serves it to all the rows of that head
@@ -91,8 +92,11 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 if (is_q) { sh_q[FUSED ? vec : 0][FUSED ? lane : 0] = a; sh_q[FUSED ? vec : 0][FUSED ? lane + half : 0] = b; }
                 else {
                     bf16_t* o = (is_k ? kc : vc) + (((int64_t)slot * kv_heads + kh) * max_pos + hi) * D;
-                    o[lane] = f32_to_bf16(a);
-                    o[lane + half] = f32_to_bf16(b);
+                    const bf16_t ra = f32_to_bf16(a), rb = f32_to_bf16(b);
+                    o[lane] = ra;
+                    o[lane + half] = rb;
+                    sh_kv[is_k ? 0 : 1][FUSED ? lane : 0] = ra;         // ... and kept in LDS: the workgroup attends to its own new
+                    sh_kv[is_k ? 0 : 1][FUSED ? lane + half : 0] = rb;  // row without a round trip through global memory
                 }
             }
         }
@@ -121,7 +125,10 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int p = p0 + u * STEP;
-                if (p > pre_last && p <= hi) {
+                if (p == hi) {
+                    kk[u] = *reinterpret_cast<const u4_t*>(&sh_kv[0][FUSED ? sub * 8 : 0]);
+                    vv[u] = *reinterpret_cast<const u4_t*>(&sh_kv[1][FUSED ? sub * 8 : 0]);
+                } else if (p > pre_last && p < hi) {
                     const int64_t po = (int64_t)p * D + (p < prefix_len ? pdelta : 0);
                     kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
                     vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
