@@ -263,8 +263,14 @@ RT_API int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t 
 RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed,
                            int32_t frame, int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out);
 
-/* Tuning knobs of the decode GEMM (negative / zero = leave unchanged) and a back-to-back launch microbenchmark that
- * cycles over n_mats weight matrices (choose n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
+/* A/B switches for measurements and tests (process-wide; the defaults are the fast path).  First argument:
+ *   0..2 legacy skinny-GEMM variant (second argument: its waves per CU) | 100/101 legacy 9-launch / column-owner decode |
+ *   200/201 eager / hipGraph frames | 300/301 predictor weights cacheable / non-temporal | 40n n decode lanes |
+ *   500 automatic, 501/502/504 forced sub-tile split of narrow decode GEMMs | 600/601 128x96 codec tiles off/on |
+ *   700/701 32-row / 64-row decode GEMM launches | 800/801 separate / fused sampler + next-input embedding |
+ *   90n prefill split-K target of n workgroups per CU | 1000/1001 XCD-aware tile order of the tiled GEMM off/on
+ * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
+ * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);
 RT_API int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_norm, int32_t epi, int32_t n_mats, int32_t iters,
                              double* avg_us, int64_t* stamps8);
