@@ -196,6 +196,7 @@ def to_native(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str, tor
     n = len(c.upsample_rates) + 1
     out["codec.fin_a"], out["codec.fin_ib"] = snake(state[f"codec.decoder.{n}.alpha"], state[f"codec.decoder.{n}.beta"])
     out["codec.fin_w"] = conv_mat(state[f"codec.decoder.{n + 1}.conv.weight"])                  # [1, 7*C]
+    out["codec.fin_wv"] = f32(out["codec.fin_w"]).reshape(-1)                                     # the same taps as a plain vector
     out["codec.fin_b"] = f32(state[f"codec.decoder.{n + 1}.conv.bias"])
     return out
 

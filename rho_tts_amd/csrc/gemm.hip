@@ -534,6 +534,7 @@ int g_col_rows64 = 1;           // 1: one 64-row decode GEMM launch for the pred
 int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
 int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
 int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
+int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its own LDS-window kernel
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)

@@ -77,6 +77,7 @@ extern int g_use_graph;
 extern int g_pred_nt;
 extern int g_decode_lanes;
 extern int g_tile96;
+extern int g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
 extern int g_xcd_order;
 extern int g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
 extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
@@ -233,4 +234,7 @@ int launch_dwconv_ln(rt_ctx* ctx, const float* x, int B, int T, int C, const flo
 int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q, int H, const int32_t* codes /*[B][T][Q]*/,
                            int64_t rows, float* out_f32);
 
+// last conv of the codec decoder (C -> 1, k = 7, causal) + clamp on hi / lo operand planes [B][T][C]; w = [7][C] f32
+bool launch_final_conv_ok(int C);
+int launch_final_conv(rt_ctx* ctx, const bf16_t* hi, const bf16_t* lo, int B, int T, int C, const float* w, const float* bias, float* wav);
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out);

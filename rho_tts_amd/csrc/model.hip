@@ -231,6 +231,7 @@ void declare_slots(rt_model* m) {
     add_slot(m, "codec.fin_a", K_VEC, cl, 1);
     add_slot(m, "codec.fin_ib", K_VEC, cl, 1);
     add_slot(m, "codec.fin_w", K_GEMM, 1, 7 * (int64_t)cl);   // last conv (C -> 1, k = 7) as a one-column GEMM
+    add_slot(m, "codec.fin_wv", K_VEC, 7 * (int64_t)cl, 1);  // ... and as a plain f32 vector for the dedicated last-conv kernel
     add_slot(m, "codec.fin_b", K_VEC, 1, 1);
 }
 
@@ -1311,8 +1312,12 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
         const int cl = m->dec_ch.back();
         GemmA a; a.ptr = s_in.hi; a.ptr_lo = s_in.lo; a.split = 1; a.M = (int64_t)B * Tc; a.Cin = cl; a.taps = 7; a.tap_stride = 1; a.tap_offset = -6;
         a.rows_out = (int)Tc; a.rows_in = (int)Tc;
-        GemmEpi e; e.bias = VEC(m, "codec.fin_b"); e.act = ACT_CLAMP1; e.out_f32 = wav_tmp; e.ldc = 1;
-        RT_TRY(launch_gemm(ctx, a, PW(m, "codec.fin_w"), e));
+        if (launch_final_conv_ok(cl) && g_final_conv) {
+            RT_TRY(launch_final_conv(ctx, s_in.hi, s_in.lo, B, (int)Tc, cl, VEC(m, "codec.fin_wv"), VEC(m, "codec.fin_b"), wav_tmp));
+        } else {
+            GemmEpi e; e.bias = VEC(m, "codec.fin_b"); e.act = ACT_CLAMP1; e.out_f32 = wav_tmp; e.ldc = 1;
+            RT_TRY(launch_gemm(ctx, a, PW(m, "codec.fin_w"), e));
+        }
     }
     RT_HIP(ctx, hipMemcpy2DAsync(d_wav, (size_t)wav_stride * 4, wav_tmp, (size_t)Tc * 4, (size_t)Tc * 4, B, hipMemcpyDeviceToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

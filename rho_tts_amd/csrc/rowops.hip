@@ -345,6 +345,48 @@ __global__ __launch_bounds__(256) void k_code_embed_mean(const bf16_t* __restric
 }
 
 
+// Last conv of the codec decoder (C channels -> 1, k = 7, causal) + clamp(-1, 1), input as the hi / lo bf16 planes the previous
+// epilogue wrote.  As a one-column GEMM it wasted 127 of 128 tile columns (1.0 ms at 2.7 M samples); here a workgroup owns 128
+// consecutive samples of one item: the (128 + 6) x C input window is summed (hi + lo, exact in f32) into LDS once with
+// coalesced 16-B loads, then every thread does half a sample's 7 x C dot product out of LDS (row stride C + 1).
+__global__ __launch_bounds__(256) void k_final_conv(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int T, int C,
+                                                    const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wav) {
+    extern __shared__ float sm[];
+    const int stride = C + 1;
+    float* tile = sm;
+    float* wt = sm + 134 * stride;
+    const int b = blockIdx.y, t0 = blockIdx.x * 128, tid = threadIdx.x;
+    for (int i = tid; i < 7 * C; i += 256) wt[i] = w[i];
+    const int C8 = C >> 3;
+    for (int idx = tid; idx < 134 * C8; idx += 256) {
+        const int row = idx / C8, c = (idx - row * C8) * 8, t = t0 - 6 + row;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) {
+            const int64_t o = ((int64_t)b * T + t) * C + c;
+            const uint4 h = *reinterpret_cast<const uint4*>(hi + o), l = *reinterpret_cast<const uint4*>(lo + o);
+            const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+                v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[row * stride + c + e] = v[e];
+    }
+    __syncthreads();
+    const int s = tid >> 1, half = tid & 1, ch = C >> 1;
+    float acc = 0.f;
+    for (int k = 0; k < 7; ++k) {
+        const float* x = tile + (s + k) * stride + half * ch;
+        const float* ww = wt + k * C + half * ch;
+        for (int c = 0; c < ch; ++c) acc += x[c] * ww[c];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    const int t = t0 + s;
+    if (half == 0 && t < T) wav[(int64_t)b * T + t] = fminf(1.f, fmaxf(-1.f, acc + bias[0]));
+}
+
 __global__ void k_f32_to_bf16(const float* __restrict__ x, int64_t n, bf16_t* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = f32_to_bf16(x[i]);
@@ -466,6 +508,17 @@ int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q
     return RT_OK;
 }
 
+
+bool launch_final_conv_ok(int C) { return C % 16 == 0 && (size_t)(134 * (C + 1) + 7 * C) * 4 <= 64 * 1024; }
+
+int launch_final_conv(rt_ctx* ctx, const bf16_t* hi, const bf16_t* lo, int B, int T, int C, const float* w, const float* bias, float* wav) {
+    if (B <= 0 || T <= 0) return RT_OK;
+    if (!launch_final_conv_ok(C)) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "final conv: %d channels do not fit the LDS window", C);
+    const size_t lds = (size_t)(134 * (C + 1) + 7 * C) * 4;
+    hipLaunchKernelGGL(k_final_conv, dim3((T + 127) / 128, B), dim3(256), lds, ctx->stream, hi, lo, T, C, w, bias, wav);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
 
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out) {
     if (n <= 0) return RT_OK;
