@@ -335,3 +335,34 @@ def test_engine_chunked_vocode_matches_oracle_chunked_decode(ctx):
             assert rmse < 1e-3, (c.shape[0], rmse)
     finally:
         eng.close()
+
+
+def test_batches_above_32_fall_back_to_the_split_k_path(ctx):
+    """2B > 64 rows do not fit the column-owner launches: the legacy split-K decode path takes over.  Teacher-forced logits of
+    a 36-item batch agree with the same items decoded in two 18-item batches on the column path."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg = config.PRESETS["tiny"]()
+    nm, _ = build(ctx, cfg, max_batch=40)
+    try:
+        set_voice(nm, make_voice(cfg, True))
+        g = torch.Generator().manual_seed(17)
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(n),), generator=g)] for n in torch.randint(1, 7, (36,), generator=g)]
+        frames = [4] * 36
+        sp = RtSampling(1, 0.9, 50, 1.0, 1.05)
+        free = nm.generate(texts[:18], frames[:18], sp, seed=5, item_ids=list(range(18))) + \
+            nm.generate(texts[18:], frames[18:], sp, seed=5, item_ids=list(range(18, 36)))
+        greedy = RtSampling(0, 1, 1, 1, 1)
+        out, tr_big = nm.generate(texts, frames, greedy, forced_codes=free, trace=True)
+        assert [o.shape[0] for o in out] == frames
+        _, tr_a = nm.generate(texts[:18], frames[:18], greedy, forced_codes=free[:18], trace=True)
+        _, tr_b = nm.generate(texts[18:], frames[18:], greedy, forced_codes=free[18:], trace=True)
+        V0 = cfg.codec.codebook_size
+        for key in ("talker", "predictor"):
+            big = tr_big[key].cpu()
+            small = torch.cat([tr_a[key].cpu(), tr_b[key].cpu()], dim=-2)       # the batch axis
+            if key == "talker":
+                big, small = big[..., :V0], small[..., :V0]
+            assert big.shape == small.shape
+            assert float((big - small).abs().max()) <= 0.06 * float(small.std()) + 1e-6
+    finally:
+        nm.close()
