@@ -222,6 +222,108 @@ __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B ro
     return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
 }
 
+// Fused epilogue of one wave's MT x NTT accumulator tiles (shared by k_gemm_tiled and k_conv_win).
+template <int MT, int NTT>
+__device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[MT][NTT], int64_t m0, int n0, int wm, int wn, int r, int h) {
+    // ---- epilogue.  Every option of GemmEpi is uniform over the launch, so each one is tested ONCE per 32x32 accumulator
+    // tile with the 16-element loops inside (tested per element, the option branches and 64-bit index arithmetic made the
+    // epilogue ~220 instructions per output - several times the cost of the K loop for the codec decoder's short-K convs).
+    const GemmEpi& e = g.e;
+    const int64_t M = g.a.M, ldc = e.ldc;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt) {
+            const int n = n0 + (wn * NTT + nt) * 32 + r;
+            if (n >= g.N) continue;
+            const int64_t mb = m0 + (wm * MT + mt) * 32 + 4 * h;       // row of accumulator element 0
+            const int64_t ob = mb * ldc + n;
+            // element i sits (i & 3) + 8 * (i >> 2) rows below
+#define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
+            bool ok[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ok[i] = mb + RT_ROW(i) < M;
+            if (e.split_k > 1) {
+                float* slab = e.out_f32 + (int64_t)blockIdx.z * M * ldc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) slab[ob + RT_ROW(i) * ldc] = acc[mt][nt][i];
+                continue;
+            }
+            // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads issued
+            // between the stores would be serialised behind them
+            float res[16];
+            if (e.residual) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[i] = ok[i] ? e.residual[ob + RT_ROW(i) * ldc] : 0.f;
+            }
+            const float bias = e.bias ? e.bias[n] : 0.f;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i] + bias;
+            if (e.act == ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
+            } else if (e.act == ACT_GELU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
+            } else if (e.act == ACT_SNAKE) {
+                const float sa = e.snake_a[n], sib = e.snake_ib[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * sa); v[i] = v[i] + sib * sn * sn; }
+            } else if (e.act == ACT_CLAMP1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fminf(1.f, fmaxf(-1.f, v[i]));
+            }
+            if (e.scale) {
+                const float scale = e.scale[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] *= scale;
+            }
+            if (e.residual) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] += res[i];
+            }
+            if (e.out_f32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_f32[ob + RT_ROW(i) * ldc] = v[i];
+            }
+            if (e.out_bf16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+            }
+            if (e.out_hi) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bf16_t hi = f32_to_bf16(v[i]);
+                    const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
+                    if (ok[i]) { e.out_hi[ob + RT_ROW(i) * ldc] = hi; e.out_lo[ob + RT_ROW(i) * ldc] = lo; }
+                }
+            }
+            if (e.out2_hi || e.out2_bf16 || e.out2_f32) {
+                const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
+                if (e.out2_hi) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bf16_t hi = f32_to_bf16(v[i]);
+                        const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
+                        if (ok[i]) { e.out2_hi[ob + RT_ROW(i) * ldc] = hi; e.out2_lo[ob + RT_ROW(i) * ldc] = lo; }
+                    }
+                }
+                if (e.out2_bf16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+                }
+                if (e.out2_f32) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_f32[ob + RT_ROW(i) * ldc] = v[i];
+                }
+            }
+#undef RT_ROW
+        }
+}
+
 // SPLIT: the f32 A operand is fed as two bf16 planes, hi = bf16(x) and lo = bf16(x - hi), and every B fragment
 // is multiplied with both (2x MFMA work): products stay exact, activation precision goes from 2^-9 to ~2^-17.
 // Used by the codec decoder, whose waveform has to agree with the f32-activation oracle to RMSE < 1e-3.
@@ -395,103 +497,155 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tiled(TiledArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue.  Every option of GemmEpi is uniform over the launch, so each one is tested ONCE per 32x32 accumulator
-    // tile with the 16-element loops inside (tested per element, the option branches and 64-bit index arithmetic made the
-    // epilogue ~220 instructions per output - several times the cost of the K loop for the codec decoder's short-K convs).
-    const GemmEpi& e = g.e;
-    const int64_t M = g.a.M, ldc = e.ldc;
+    tile_epilogue<MT, NTT>(g, acc, m0, n0, wm, wn, r, h);
+}
+
+// Causal dilated conv as an implicit GEMM with the input window held in LDS (codec decoder k=7 convs, operand = hi / lo bf16
+// planes).  k_gemm_tiled walks K = tap x channel in 32-wide steps and re-loads a shifted copy of the same input rows for every
+// tap: 7 global loads, 7 barriers and 7 exposed round trips per 32 channels.  Here a workgroup loads the rows its 128 outputs
+// can see - 128 + (taps-1)*dilation of them - ONCE per 32-channel chunk, and the taps are fragment reads at shifted LDS rows:
+// one barrier per `taps` MFMA steps, the next chunk's window in flight during all of them.
+// Requires rows_in == rows_out, tap_offset = -(taps-1)*tap_stride, Cin % 32 == 0, (taps-1)*tap_stride <= 64, split_k = 1.
+constexpr int WIN_ROWS = BM + 64;
+template <int WGM, int WGN, int MT, int NTT>
+__global__ __launch_bounds__(256, 3) void k_conv_win(TiledArgs g) {
+    static_assert(WGM * WGN == 4 && WGM * MT * 32 == BM, "4 waves, 128 rows");
+    constexpr int BNT = WGN * NTT * 32;
+    constexpr int PLANE = WIN_ROWS * 64;                  // bytes per plane and stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w / WGN, wn = w % WGN;
+    const int r = lane & 31, h = lane >> 5;
+    int64_t rt = blockIdx.x;
+    int ct = blockIdx.y;
+    if (g.xcd_order) {                                    // same XCD-aware tile order as k_gemm_tiled
+        const int64_t L = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = (int)(L & 7);
+        const int64_t j = L >> 3;
+        ct = (int)(j % gridDim.y);
+        rt = (j / gridDim.y) * 8 + xcd;
+        if (rt * BM >= g.a.M) return;
+    }
+    const int64_t m0 = rt * BM;
+    const int n0 = ct * BNT;
+    const int taps = g.a.taps, stride = g.a.tap_stride, Cin = g.a.Cin;
+    const int halo = (taps - 1) * stride, WR = BM + halo, n_cc = Cin >> 5;
+    const bf16_t* __restrict__ hi = reinterpret_cast<const bf16_t*>(g.a.ptr);
+    const bf16_t* __restrict__ lo = reinterpret_cast<const bf16_t*>(g.a.ptr_lo);
+
+    // ---- window staging: piece p = tid + 256 i -> (window row p >> 2, 16-B slot p & 3); global row = m0 - halo + row
+    int64_t p_off[3];
+    bool p_ok[3];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int i = 0; i < 3; ++i) {
+        const int p = tid + i * 256, row = p >> 2, slot = p & 3;
+        const int64_t gr = m0 - halo + row;
+        p_ok[i] = row < WR && gr >= 0 && gr < g.a.M;
+        p_off[i] = gr * Cin + slot * 8;
+    }
+    auto load_win = [&](int cc, s8_t (&a)[3], s8_t (&l)[3]) {
 #pragma unroll
-        for (int nt = 0; nt < NTT; ++nt) {
-            const int n = n0 + (wn * NTT + nt) * 32 + r;
-            if (n >= g.N) continue;
-            const int64_t mb = m0 + (wm * MT + mt) * 32 + 4 * h;       // row of accumulator element 0
-            const int64_t ob = mb * ldc + n;
-            // element i sits (i & 3) + 8 * (i >> 2) rows below
-#define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
-            bool ok[16];
+        for (int i = 0; i < 3; ++i) {
+            if (p_ok[i]) {
+                a[i] = *reinterpret_cast<const s8_t*>(hi + p_off[i] + cc * 32);
+                l[i] = *reinterpret_cast<const s8_t*>(lo + p_off[i] + cc * 32);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) ok[i] = mb + RT_ROW(i) < M;
-            if (e.split_k > 1) {
-                float* slab = e.out_f32 + (int64_t)blockIdx.z * M * ldc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) slab[ob + RT_ROW(i) * ldc] = acc[mt][nt][i];
-                continue;
+                for (int j = 0; j < 8; ++j) { a[i][j] = 0; l[i][j] = 0; }
             }
-            // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads issued
-            // between the stores would be serialised behind them
-            float res[16];
-            if (e.residual) {
+        }
+    };
+    auto store_win = [&](int buf, const s8_t (&a)[3], const s8_t (&l)[3]) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) res[i] = ok[i] ? e.residual[ob + RT_ROW(i) * ldc] : 0.f;
+        for (int i = 0; i < 3; ++i) {
+            const int p = tid + i * 256;
+            if ((p >> 2) < WIN_ROWS) {
+                *reinterpret_cast<s8_t*>(lds + buf * 2 * PLANE + lds_a_off(p >> 2, p & 3)) = a[i];
+                *reinterpret_cast<s8_t*>(lds + buf * 2 * PLANE + PLANE + lds_a_off(p >> 2, p & 3)) = l[i];
             }
-            const float bias = e.bias ? e.bias[n] : 0.f;
-            float v[16];
+        }
+    };
+    // ---- B fragments straight from the packed weights: k tile of (tap, chunk, kk) = (tap * Cin + 32 cc) / 16 + kk
+    const int nt_base = (n0 >> 5) + wn * NTT;
+    auto load_b = [&](int tap, int cc, s8_t (&b)[NTT][2]) {
+        const int t_k0 = (tap * Cin + cc * 32) >> 4;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i] + bias;
-            if (e.act == ACT_SILU) {
+        for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
-            } else if (e.act == ACT_GELU) {
+            for (int kk = 0; kk < 2; ++kk) {
+                const int t_n = nt_base + nt;
+                if (t_n < g.NT) b[nt][kk] = *(reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)t_n * g.KT + t_k0 + kk) * 64 + lane);
+                else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
-            } else if (e.act == ACT_SNAKE) {
-                const float sa = e.snake_a[n], sib = e.snake_ib[n];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * sa); v[i] = v[i] + sib * sn * sn; }
-            } else if (e.act == ACT_CLAMP1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fminf(1.f, fmaxf(-1.f, v[i]));
-            }
-            if (e.scale) {
-                const float scale = e.scale[n];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] *= scale;
-            }
-            if (e.residual) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] += res[i];
-            }
-            if (e.out_f32) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_f32[ob + RT_ROW(i) * ldc] = v[i];
-            }
-            if (e.out_bf16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
-            }
-            if (e.out_hi) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bf16_t hi = f32_to_bf16(v[i]);
-                    const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
-                    if (ok[i]) { e.out_hi[ob + RT_ROW(i) * ldc] = hi; e.out_lo[ob + RT_ROW(i) * ldc] = lo; }
+                    for (int j = 0; j < 8; ++j) b[nt][kk][j] = 0;
                 }
             }
-            if (e.out2_hi || e.out2_bf16 || e.out2_f32) {
-                const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+    };
+    // time index of this lane's fragment rows: a tap reaching before the start of its item reads zeros
+    int t_row[MT];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
-                if (e.out2_hi) {
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = m0 + (wm * MT + mt) * 32 + r;
+        t_row[mt] = (int)(m % g.a.rows_out);
+    }
+
+    f16_t acc[MT][NTT];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const bf16_t hi = f32_to_bf16(v[i]);
-                        const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
-                        if (ok[i]) { e.out2_hi[ob + RT_ROW(i) * ldc] = hi; e.out2_lo[ob + RT_ROW(i) * ldc] = lo; }
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTT; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    s8_t ra[3], rl[3], rb[NTT][2], rb_next[NTT][2];
+    load_win(0, ra, rl);
+    load_b(0, 0, rb);
+    store_win(0, ra, rl);
+    __syncthreads();
+    for (int cc = 0; cc < n_cc; ++cc) {
+        const int buf = cc & 1;
+        const bool more = cc + 1 < n_cc;
+        if (more) load_win(cc + 1, ra, rl);
+        for (int tap = 0; tap < taps; ++tap) {
+            const bool last = tap + 1 == taps;
+            if (!last) load_b(tap + 1, cc, rb_next);
+            else if (more) load_b(0, cc + 1, rb_next);
+            const int reach = (taps - 1 - tap) * stride;          // rows this tap looks back
+            s8_t fa[MT][2], fl[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int wrow = (wm * MT + mt) * 32 + r + tap * stride;
+                const bool ok = t_row[mt] >= reach;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * 2 * PLANE + lds_a_off(wrow, kk * 2 + h));
+                    fl[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * 2 * PLANE + PLANE + lds_a_off(wrow, kk * 2 + h));
+                    if (!ok) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { fa[mt][kk][j] = 0; fl[mt][kk][j] = 0; }
                     }
                 }
-                if (e.out2_bf16) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
-                }
-                if (e.out2_f32) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_f32[ob + RT_ROW(i) * ldc] = v[i];
-                }
             }
-#undef RT_ROW
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTT; ++nt) {
+                        acc[mt][nt] = mfma32(fa[mt][kk], rb[nt][kk], acc[mt][nt]);
+                        acc[mt][nt] = mfma32(fl[mt][kk], rb[nt][kk], acc[mt][nt]);
+                    }
+            if (!last || more) {
+#pragma unroll
+                for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) rb[nt][kk] = rb_next[nt][kk];
+            }
         }
+        if (more) store_win(buf ^ 1, ra, rl);
+        __syncthreads();
+    }
+    tile_epilogue<MT, NTT>(g, acc, m0, n0, wm, wn, r, h);
 }
 
 }  // namespace
@@ -535,6 +689,7 @@ int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one laun
 int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
 int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
 int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its own LDS-window kernel
+int g_conv_win = 1;             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
@@ -610,6 +765,14 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     if (a.split && !a.is_f32 && !a.ptr_lo) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand or a low plane");
     if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || !e.snake2_a || !e.snake2_ib)) || ((e.out_hi || e.out2_hi) && e.split_k > 1))
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");
+    // codec decoder k>1 convs on operand planes: input window in LDS (k_conv_win)
+    if (g_conv_win && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 && a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out &&
+        a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 && e.split_k == 1 && a.M % a.rows_out == 0) {
+        if (narrow) hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((k_conv_win<2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    }
 #define RT_TILED(AF, SP)                                                                                          \
     do {                                                                                                          \
         if (narrow) hipLaunchKernelGGL((k_gemm_tiled<AF, SP, 4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);   \

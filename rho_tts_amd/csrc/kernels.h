@@ -77,6 +77,7 @@ extern int g_use_graph;
 extern int g_pred_nt;
 extern int g_decode_lanes;
 extern int g_tile96;
+extern int g_conv_win;
 extern int g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
 extern int g_xcd_order;
 extern int g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
