@@ -249,7 +249,8 @@ RT_API int rt_profile_read(rt_model* m, int64_t* n_launches, double* total_ms, d
  * Exercise single kernels against a float32 reference (tests/test_kernels_gpu.py).  All pointers are HBM.
  * rt_debug_gemm: out[M][N] (f32) = A . W^T for a row-major bf16 W[N][K=taps*cin]; A is the implicit-GEMM view
  * of a channels-last activation [batch][rows_in][cin] (bf16; f32 when a_is_f32 = 1; f32 fed as hi+lo bf16 planes
- * when a_is_f32 = 2): output row (b, t) reads input
+ * when a_is_f32 = 2; a_is_f32 = 3: d_a holds the bf16 hi plane followed by the bf16 lo plane, as a producing epilogue
+ * writes them): output row (b, t) reads input
  * rows t + tap_offset + tap*tap_stride, zero outside [0, rows_in).  mode 0: LDS-tiled kernel (split_k slabs are
  * summed on return), mode 1: weight-streaming skinny kernel (plain A only, M <= 64). */
 RT_API int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int32_t cin, int32_t taps, int32_t tap_stride,

@@ -52,8 +52,12 @@ int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int
                 if (!rc) rc = launch_reduce_slabs(ctx, slabs, split_k, M, N, d_bias, act, d_out, nullptr);
             }
         } else {
-            GemmA a; a.ptr = d_a; a.is_f32 = a_is_f32 != 0; a.split = a_is_f32 == 2; a.M = M; a.Cin = cin; a.taps = taps; a.tap_stride = tap_stride; a.tap_offset = tap_offset;
+            GemmA a; a.ptr = d_a; a.is_f32 = a_is_f32 == 1 || a_is_f32 == 2; a.split = a_is_f32 >= 2; a.M = M; a.Cin = cin; a.taps = taps; a.tap_stride = tap_stride; a.tap_offset = tap_offset;
             a.rows_out = rows_out; a.rows_in = rows_in;
+            if (a_is_f32 == 3) {     // operand planes: the bf16 hi plane, then the bf16 lo plane, each [input rows][cin]
+                const int64_t in_rows = rows_out > 0 ? (M / rows_out) * rows_in : M;
+                a.ptr_lo = (const bf16_t*)d_a + in_rows * cin;
+            }
             GemmEpi e; e.ldc = N;
             if (split_k <= 1) {
                 e.bias = d_bias; e.act = act; e.out_f32 = d_out; e.split_k = 1;

@@ -108,6 +108,35 @@ def test_causal_dilated_conv_as_gemm(ctx, C_in, C_out, dil, T, B):
     assert float((out.view(B, T, C_out).cpu() - ref.transpose(1, 2)).abs().max()) < 3e-3
 
 
+@pytest.mark.parametrize("C_in,C_out,dil,T,B", [(96, 96, 3, 333, 3), (32, 64, 9, 40, 1), (192, 192, 9, 700, 2), (64, 128, 1, 129, 2),
+                                               (96, 96, 9, 128, 4), (384, 384, 3, 77, 5)])
+def test_causal_dilated_conv_on_operand_planes(ctx, C_in, C_out, dil, T, B):
+    """The codec decoder's k = 7 convs read hi / lo bf16 operand planes and keep their input window in LDS (k_conv_win; tile
+    tails, item starts inside a tile, windows that reach into the previous item): == F.conv1d on the f32 input to split
+    precision.  rt_debug_tune(1200) runs the same planes through the per-tap kernel."""
+    x = rnd(B, T, C_in, seed=11)
+    w = rnd(C_out, C_in, 7, scale=0.1, seed=12).to(torch.bfloat16)
+    wm = w.permute(0, 2, 1).reshape(C_out, 7 * C_in).contiguous().cuda()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    planes = torch.cat([hi.reshape(-1), lo.reshape(-1)]).cuda()
+    ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.transpose(1, 2), (6 * dil, 0)), w.float(), dilation=dil).transpose(1, 2)
+    outs = []
+    try:
+        for code in (1201, 1200):
+            ctx.lib.rt_debug_tune(code, 0)
+            out = torch.empty(B * T, C_out, device="cuda")
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.rt_debug_gemm(ctx.handle, planes.data_ptr(), 3, B * T, C_in, 7, dil, -6 * dil, T, T, wm.data_ptr(), C_out, None, 0,
+                                            out.data_ptr(), 0, 1), "rt_debug_gemm")
+            outs.append(out.view(B, T, C_out).cpu())
+    finally:
+        ctx.lib.rt_debug_tune(1201, 0)
+    for out in outs:
+        assert float((out - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("C_in,C_out,r,T,B", [(32, 16, 3, 20, 2), (64, 32, 8, 45, 3), (96, 48, 2, 7, 1)])
 def test_transposed_conv_as_gemm(ctx, C_in, C_out, r, T, B):
     """ConvTranspose1d(k = 2r, stride r) trimmed r on both sides == 2-tap GEMM over (x[m], x[m+1])."""
