@@ -260,6 +260,27 @@ RT_API int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t
 RT_API int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
                               const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t window, const void* d_k, const void* d_v,
                               int32_t slots, int32_t max_pos, void* d_out_bf16);
+/* The dominant decode kernel on its own (gemm_col.hip k_gemm_col; launched as model.hip launches it: row blocks of <= 64,
+ * production sub-tile split when split = 0).  Row-major operands; the hook converts to / from the fragment-tiled layout.
+ *   A [M][K] bf16, W [N][K] bf16 (epi 2: gate rows [0, N/2) then up rows), M <= 64, K % 32 == 0, row_off % 16 == 0
+ *   d_rowsq [M][rowsq_n] or NULL: partial sums of squares of the pre-norm row; acc rows are scaled by rsqrt(sum/K + eps)
+ *   epi 0 STORE: d_x [M][N] f32 out = scale_row * (A W^T) + bias
+ *   epi 1 RESID: d_x [M][N] f32 in/out: x += scale .* (scale_row * (A W^T) + bias); d_next_bf16 [M][N] = bf16(next_norm_w .* x);
+ *                d_rowsq_out [M][ceil(N/16)*split] partial sums of squares of the new x
+ *   epi 2 SILU : d_act_bf16 [M][N/2] = bf16(silu(g) * u)
+ * nt: 1 = non-temporal weight loads (talker), 0 = cacheable (predictor). */
+RT_API int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32_t K, const void* d_w_bf16, int32_t N, int32_t epi, int32_t split,
+                             int32_t row_off, int32_t nt, const float* d_rowsq, int32_t rowsq_n, float eps, const float* d_bias,
+                             const float* d_scale, float* d_x, const float* d_next_norm_w, void* d_next_bf16, float* d_rowsq_out,
+                             void* d_act_bf16);
+/* The decode step's fused attention launch: qkv [M][(heads+2kv)*d] f32 (raw projections), q/k norm weights [d] or NULL,
+ * cos/sin [max_pos][d/2]; row r is sequence slot row_slot[r] at position row_pos[r] + pos_add: its K/V row is appended to the
+ * caches [slots][kv_heads][max_pos][d] bf16, then it attends to positions [0, pos]; positions < prefix_len are read from
+ * prefix_slot (-1: no shared prefix).  out [M][heads*d] bf16 row-major. */
+RT_API int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                                    const float* d_q_norm_w, const float* d_k_norm_w, float eps, const float* d_cos, const float* d_sin,
+                                    const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t pos_add, void* d_k, void* d_v,
+                                    int32_t slots, int32_t max_pos, int32_t prefix_slot, int32_t prefix_len, void* d_out_bf16);
 /* One draw per row: logits [M][V] f32 -> tokens [M].  item ids 0..M-1. */
 RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed,
                            int32_t frame, int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out);

@@ -23,6 +23,17 @@ HIP path is compared with.
 Numerics: weights are bf16 values held in float32 (the reference loads the
 model with dtype=torch.bfloat16, providers/qwen.py:163), activations and
 accumulation float32.
+
+``OracleModel(..., act_bf16=True)`` additionally rounds activations to bf16 at
+the points where a bf16 model does (the reference runs the model in
+``dtype=torch.bfloat16``: every Linear input and the KV cache are bf16 there):
+GEMM inputs, attention output, SwiGLU product, cached K/V.  The rounding points
+follow the HIP path's (DESIGN.md "Precision policy"): the prompt prefill rounds
+``bf16(rmsnorm(x) * w)``, a decode step rounds ``bf16(w * x)`` and applies the
+row scale to the f32 accumulator.  With the same rounding points on both sides
+what is left between oracle and GPU is accumulation order and the last bit of
+exp / rsqrt, which is what lets tests/test_model_shapes_gpu.py hold the
+teacher-forced logits to 0.5 % of their sigma instead of 4 %.
 """
 from __future__ import annotations
 
@@ -50,6 +61,24 @@ class Voice:
 def rms_norm(x, w, eps):
     v = x.pow(2).mean(-1, keepdim=True)
     return w * (x * torch.rsqrt(v + eps))
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def normed_matmul(x, w_norm, eps, mats, mode):
+    """[rmsnorm(x; w_norm) @ W.T for W in mats] with the rounding points of ``mode``:
+    None: float32 throughout; "prefill": the GEMM input is bf16(rmsnorm(x) * w); "decode": the GEMM input is
+    bf16(w * x) and the RMSNorm row scale multiplies the f32 product (gemm_col.hip's post-scale)."""
+    if mode == "decode":
+        a = bf16_round(w_norm * x)
+        inv = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+        return [(a @ W.T) * inv for W in mats]
+    h = rms_norm(x, w_norm, eps)
+    if mode == "prefill":
+        h = bf16_round(h)
+    return [h @ W.T for W in mats]
 
 
 def rope_table(head_dim: int, theta: float, n_pos: int):
@@ -81,10 +110,12 @@ class Stack:
         self.v_cache = [torch.zeros(batch, d.kv_heads, max_pos, d.head_dim) for _ in range(d.layers)]
         self.cos, self.sin = rope_table(d.head_dim, d.rope_theta, max_pos)
 
-    def forward(self, x: torch.Tensor, pos: torch.Tensor, final_norm=True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, pos: torch.Tensor, final_norm=True, mode=None) -> torch.Tensor:
         """x [B, T, H]; pos [B, T] absolute positions (also the cache rows written).
-        Row (b, t) attends cache rows j <= pos[b, t] (and > pos - window when windowed)."""
+        Row (b, t) attends cache rows j <= pos[b, t] (and > pos - window when windowed).
+        mode: bf16 rounding points (see normed_matmul); None = float32 activations."""
         d, W, p = self.d, self.W, self.p
+        rnd = bf16_round if mode else (lambda t: t)
         B, T, _ = x.shape
         cos, sin = self.cos[pos][:, None], self.sin[pos][:, None]            # [B,1,T,d/2]
         n_ctx = int(pos.max()) + 1
@@ -95,34 +126,37 @@ class Stack:
         bi = torch.arange(B)[:, None].expand(B, T)
         for i in range(d.layers):
             lp = f"{p}.layers.{i}"
-            h = rms_norm(x, W[f"{lp}.input_layernorm.weight"], d.rms_eps)
-            q = (h @ W[f"{lp}.self_attn.q_proj.weight"].T).view(B, T, d.heads, d.head_dim)
-            k = (h @ W[f"{lp}.self_attn.k_proj.weight"].T).view(B, T, d.kv_heads, d.head_dim)
-            v = (h @ W[f"{lp}.self_attn.v_proj.weight"].T).view(B, T, d.kv_heads, d.head_dim)
+            q, k, v = normed_matmul(x, W[f"{lp}.input_layernorm.weight"], d.rms_eps,
+                                    [W[f"{lp}.self_attn.q_proj.weight"], W[f"{lp}.self_attn.k_proj.weight"], W[f"{lp}.self_attn.v_proj.weight"]], mode)
+            q, k, v = q.view(B, T, d.heads, d.head_dim), k.view(B, T, d.kv_heads, d.head_dim), v.view(B, T, d.kv_heads, d.head_dim)
             if self.qk_norm:
                 q = rms_norm(q, W[f"{lp}.self_attn.q_norm.weight"], d.rms_eps)
                 k = rms_norm(k, W[f"{lp}.self_attn.k_norm.weight"], d.rms_eps)
             q = apply_rope(q.transpose(1, 2), cos, sin)                       # [B,h,T,d]
             k = apply_rope(k.transpose(1, 2), cos, sin)
-            self.k_cache[i][bi, :, pos] = k.transpose(1, 2)
-            self.v_cache[i][bi, :, pos] = v
+            self.k_cache[i][bi, :, pos] = rnd(k.transpose(1, 2))
+            self.v_cache[i][bi, :, pos] = rnd(v)
             rep = d.heads // d.kv_heads
             K = self.k_cache[i][:, :, :n_ctx].repeat_interleave(rep, dim=1)
             V = self.v_cache[i][:, :, :n_ctx].repeat_interleave(rep, dim=1)
             s = (q @ K.transpose(-1, -2)) * (d.head_dim ** -0.5)
             s = s.masked_fill(~mask[:, None], float("-inf"))
             a = torch.softmax(s, dim=-1) @ V                                  # [B,h,T,d]
-            o = a.transpose(1, 2).reshape(B, T, d.q_dim) @ W[f"{lp}.self_attn.o_proj.weight"].T
+            o = rnd(a.transpose(1, 2).reshape(B, T, d.q_dim)) @ W[f"{lp}.self_attn.o_proj.weight"].T
             if self.layer_scale:
                 o = o * W[f"{lp}.self_attn_layer_scale.scale"]
             x = x + o
-            h = rms_norm(x, W[f"{lp}.post_attention_layernorm.weight"], d.rms_eps)
-            m = (F.silu(h @ W[f"{lp}.mlp.gate_proj.weight"].T) * (h @ W[f"{lp}.mlp.up_proj.weight"].T)) \
-                @ W[f"{lp}.mlp.down_proj.weight"].T
+            gt, up = normed_matmul(x, W[f"{lp}.post_attention_layernorm.weight"], d.rms_eps,
+                                   [W[f"{lp}.mlp.gate_proj.weight"], W[f"{lp}.mlp.up_proj.weight"]], mode)
+            m = rnd(F.silu(gt) * up) @ W[f"{lp}.mlp.down_proj.weight"].T
             if self.layer_scale:
                 m = m * W[f"{lp}.mlp_layer_scale.scale"]
             x = x + m
         return rms_norm(x, W[f"{p}.norm.weight"], d.rms_eps) if final_norm else x
+
+    def head(self, x: torch.Tensor, mats, mode=None):
+        """[final_norm(x) @ W.T for W in mats] for the un-normalised stack output x (forward(..., final_norm=False))."""
+        return normed_matmul(x, self.W[f"{self.p}.norm.weight"], self.d.rms_eps, mats, mode)
 
 
 # ---------------------------------------------------------------- codec decoder ops
@@ -147,8 +181,9 @@ def snake_beta(x, alpha, beta):
 
 
 class OracleModel:
-    def __init__(self, cfg, state: Dict[str, torch.Tensor]):
+    def __init__(self, cfg, state: Dict[str, torch.Tensor], act_bf16: bool = False):
         self.cfg = cfg
+        self.act_bf16 = act_bf16
         self.W = {k: v.detach().to("cpu", torch.float32) for k, v in state.items()}
         from rho_tts_amd.weights import codec_transformer_dims
         self.talker = Stack(self.W, "talker", cfg.talker)
@@ -161,6 +196,8 @@ class OracleModel:
         W = self.W
         e = W["talker.text_embedding.weight"][torch.as_tensor(list(ids), dtype=torch.long)]
         h = F.silu(e @ W["talker.text_projection.fc1.weight"].T + W["talker.text_projection.fc1.bias"])
+        if self.act_bf16:
+            h = bf16_round(h)
         return h @ W["talker.text_projection.fc2.weight"].T + W["talker.text_projection.fc2.bias"]
 
     def codec_embed(self, ids) -> torch.Tensor:
@@ -222,25 +259,33 @@ class OracleModel:
             s[c.codec_eos_id] = False
         return s
 
-    def predictor_frame(self, past_hidden, c0, sp, seed, items, frame, forced=None, trace=None):
+    def predictor_frame(self, talker_x, c0, sp, seed, items, frame, forced=None, trace=None, past_hidden=None):
         """Residual codes 1..G-1 of one frame (predictor recurrence, sibling :2534-2608, :3137-3176).
-        past_hidden [B,H] (post-norm talker state), c0 [B].  Returns codes [B,G]."""
+        talker_x [B,H]: the talker's output row BEFORE its final norm (or None with past_hidden [B,H], the
+        post-norm state, given directly); c0 [B].  Returns codes [B,G]."""
         c, W = self.cfg, self.W
-        B = past_hidden.shape[0]
+        B = c0.shape[0]
         self.pred.alloc(B, c.n_groups + 1)
+        mode = "decode" if self.act_bf16 else None
 
         def proj(x):
             if c.has_mtp_proj:
                 return x @ W["predictor.mtp_proj.weight"].T + W["predictor.mtp_proj.bias"]
             return x
 
+        if past_hidden is not None:
+            past = proj(past_hidden)
+        elif c.has_mtp_proj:        # mtp_proj(final_norm(x)): a GEMM behind the talker's final norm
+            past = self.talker.head(talker_x, [W["predictor.mtp_proj.weight"]], mode)[0] + W["predictor.mtp_proj.bias"]
+        else:
+            past = rms_norm(talker_x, W["talker.norm.weight"], c.talker.rms_eps)
         codes = torch.zeros(B, c.n_groups, dtype=torch.long)
         codes[:, 0] = c0
-        x = torch.stack([proj(past_hidden), proj(self.codec_embed(c0))], dim=1)      # [B,2,Hp]
+        x = torch.stack([past, proj(self.codec_embed(c0))], dim=1)                   # [B,2,Hp]
         pos = torch.tensor([[0, 1]]).expand(B, 2)
-        h = self.pred.forward(x, pos)[:, -1]
+        h = self.pred.forward(x, pos, final_norm=False, mode=mode)[:, -1]
         for g in range(c.n_groups - 1):
-            logits = h @ W[f"predictor.lm_head.{g}.weight"].T
+            logits = self.pred.head(h, [W[f"predictor.lm_head.{g}.weight"]], mode)[0]
             if trace is not None:
                 trace.setdefault("pred_logits", []).append(logits.clone())
             nxt = torch.zeros(B, dtype=torch.long)
@@ -252,41 +297,66 @@ class OracleModel:
             codes[:, g + 1] = nxt
             if g < c.n_groups - 2:
                 e = proj(W[f"predictor.codec_embedding.{g}.weight"][nxt])[:, None]
-                h = self.pred.forward(e, torch.full((B, 1), g + 2))[:, -1]
+                h = self.pred.forward(e, torch.full((B, 1), g + 2), final_norm=False, mode=mode)[:, -1]
         return codes
 
     def generate(self, voice: Voice, texts: Sequence[Sequence[int]], max_frames: Sequence[int],
                  sp_talker: SamplingParams = SamplingParams(), sp_pred: Optional[SamplingParams] = None,
                  seed: int = 789, item_ids: Optional[Sequence[int]] = None, ignore_eos: bool = True,
-                 min_frames: int = 2, forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: Optional[dict] = None):
+                 min_frames: int = 2, forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: Optional[dict] = None,
+                 share_prefix: bool = False):
         """Autoregressive decode of a batch.  Returns a list of int64 code tensors [T_i, G].
 
         forced_codes: teacher forcing — the chosen codes of item b at frame t are taken from
-        forced_codes[b][t] while logits are still recorded into ``trace``."""
+        forced_codes[b][t] while logits are still recorded into ``trace``.
+        share_prefix: run the voice prefix through the talker once and copy its K/V into every item's cache
+        (attention is causal, so the prefix rows do not depend on what follows them: same numbers up to the
+        summation order of a differently shaped matmul; tests/test_oracle_model.py).  This is what makes a 460-row
+        clone prefix at batch 32 affordable on the CPU."""
         c = self.cfg
         sp_pred = sp_pred or sp_talker
         B = len(texts)
         items = list(item_ids) if item_ids is not None else list(range(B))
+        m_pre = "prefill" if self.act_bf16 else None
+        m_dec = "decode" if self.act_bf16 else None
         prefix = self.prefix_embeddings(voice)
-        prompts = [torch.cat([prefix, self.suffix_embeddings(t)], dim=0) for t in texts]
-        P = torch.tensor([p.shape[0] for p in prompts])
+        Lp = prefix.shape[0]
+        suffixes = [self.suffix_embeddings(t) for t in texts]
+        P = torch.tensor([Lp + sfx.shape[0] for sfx in suffixes])
         T_max = int(max(max_frames))
         n_pos = int(P.max()) + T_max + 1
         if n_pos > c.max_positions:
             raise RuntimeError(f"prompt length + frames = {n_pos} exceeds max_positions {c.max_positions}")
-        self.talker.alloc(B, n_pos)
-        x = torch.zeros(B, int(P.max()), c.talker.hidden)
-        for b, p in enumerate(prompts):
-            x[b, : p.shape[0]] = p
-        pos = torch.arange(int(P.max()))[None].expand(B, -1)
-        h_all = self.talker.forward(x, pos)
-        h = h_all[torch.arange(B), P - 1]                                     # [B,H] post-norm state of the last prompt row
+        if share_prefix:
+            self.talker.alloc(1, n_pos)
+            self.talker.forward(prefix[None], torch.arange(Lp)[None], final_norm=False, mode=m_pre)
+            pk = [k[:, :, :Lp].clone() for k in self.talker.k_cache]
+            pv = [v[:, :, :Lp].clone() for v in self.talker.v_cache]
+            self.talker.alloc(B, n_pos)
+            for i in range(c.talker.layers):
+                self.talker.k_cache[i][:, :, :Lp] = pk[i]
+                self.talker.v_cache[i][:, :, :Lp] = pv[i]
+            S = int(P.max()) - Lp
+            x = torch.zeros(B, S, c.talker.hidden)
+            for b, sfx in enumerate(suffixes):
+                x[b, : sfx.shape[0]] = sfx
+            x_all = self.talker.forward(x, (Lp + torch.arange(S))[None].expand(B, -1), final_norm=False, mode=m_pre)
+            xt = x_all[torch.arange(B), P - 1 - Lp]
+        else:
+            self.talker.alloc(B, n_pos)
+            x = torch.zeros(B, int(P.max()), c.talker.hidden)
+            for b, sfx in enumerate(suffixes):
+                x[b, :Lp] = prefix
+                x[b, Lp: Lp + sfx.shape[0]] = sfx
+            pos = torch.arange(int(P.max()))[None].expand(B, -1)
+            x_all = self.talker.forward(x, pos, final_norm=False, mode=m_pre)
+            xt = x_all[torch.arange(B), P - 1]                                # [B,H] last prompt row, before the final norm
         pad_t = self.text_embed([c.tts_pad_id])[0]
         seen = np.zeros((B, c.codec_vocab), dtype=bool)
         out = [[] for _ in range(B)]
         done = [False] * B
         for t in range(T_max):
-            logits = h @ self.W["talker.codec_head.weight"].T
+            logits = self.talker.head(xt, [self.W["talker.codec_head.weight"]], m_dec)[0]
             if trace is not None:
                 trace.setdefault("talker_logits", []).append(logits.clone())
             c0 = torch.zeros(B, dtype=torch.long)
@@ -302,7 +372,7 @@ class OracleModel:
             if forced_codes is not None:
                 forced_t = torch.stack([fc[min(t, fc.shape[0] - 1)] for fc in forced_codes])
             c0_in = torch.where(c0 == c.codec_eos_id, torch.zeros_like(c0), c0)  # eos rows produce no frame; keep ids in range
-            codes = self.predictor_frame(h, c0_in, sp_pred, seed, items, t, forced_t, trace)
+            codes = self.predictor_frame(xt, c0_in, sp_pred, seed, items, t, forced_t, trace)
             for b in range(B):
                 if done[b]:
                     continue
@@ -315,7 +385,7 @@ class OracleModel:
             if all(done):
                 break
             e = self.frame_embed(codes) + pad_t
-            h = self.talker.forward(e[:, None], (P + t)[:, None])[:, 0]
+            xt = self.talker.forward(e[:, None], (P + t)[:, None], final_norm=False, mode=m_dec)[:, 0]
         return [torch.stack(o) if o else torch.zeros(0, c.n_groups, dtype=torch.long) for o in out]
 
     # ------------------------------------------------------------ vocoder

@@ -26,6 +26,24 @@ __global__ void k_iota64(int64_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
 }
+
+// row-major <-> fragment-tiled (common.h tile_off) converters for the column-GEMM hook
+template <typename T>
+__global__ void k_tile_rows(const T* __restrict__ src, int M, int K, int row_off, T* __restrict__ dst) {
+    const int64_t n = (int64_t)M * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), k = (int)(i % K);
+        dst[tile_off(row_off + m, k, K)] = src[i];
+    }
+}
+template <typename T>
+__global__ void k_untile_rows(const T* __restrict__ src, int M, int K, int row_off, T* __restrict__ dst) {
+    const int64_t n = (int64_t)M * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), k = (int)(i % K);
+        dst[i] = src[tile_off(row_off + m, k, K)];
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -85,6 +103,105 @@ int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, 
     KvCache kv;
     kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
     int rc = launch_attention(ctx, d_q, M, heads, kv_heads, head_dim, d_row_slot, d_row_pos, 0, window, kv, 0, (bf16_t*)d_out_bf16);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+// The column-owner decode GEMM (k_gemm_col) on its own, launched exactly as model.hip's col_gemm launches it (row blocks of
+// 64 / 32, the production sub-tile split unless one is forced).  Row-major operands at the ABI; the hook tiles / un-tiles.
+int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32_t K, const void* d_w_bf16, int32_t N, int32_t epi, int32_t split,
+                      int32_t row_off, int32_t nt, const float* d_rowsq, int32_t rowsq_n, float eps, const float* d_bias, const float* d_scale,
+                      float* d_x, const float* d_next_norm_w, void* d_next_bf16, float* d_rowsq_out, void* d_act_bf16) {
+    if (!ctx || !d_a_bf16 || !d_w_bf16 || M < 1 || M > 64 || K < 32 || K % 32 || N < 1 || row_off < 0 || row_off % 16)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm_col: bad argument (1 <= M <= 64, K %% 32 == 0, row_off %% 16 == 0)");
+    if (epi < COL_STORE || epi > COL_SILU) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm_col: epi %d", epi);
+    if ((epi != COL_SILU && !d_x) || (epi == COL_SILU && (!d_act_bf16 || N % 32)) || (epi == COL_RESID && !d_rowsq_out))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm_col: missing output for epilogue %d", epi);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int No = epi == COL_SILU ? N / 2 : N;                  // output width
+    if (split <= 0) split = epi == COL_SILU ? col_split_silu(N, ctx->n_cu) : col_split_for(N, ctx->n_cu);
+    const int rows = (row_off + M + 31) / 32 * 32;               // tiled buffers hold whole 32-row blocks (alloc_dec_ws)
+    bf16_t *w16 = nullptr, *a_t = nullptr, *next_t = nullptr, *act_t = nullptr;
+    float *x_t = nullptr, *rowsq_all = nullptr, *rowsq_out_all = nullptr;
+    int rc = RT_OK;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : {(void*)w16, (void*)a_t, (void*)next_t, (void*)act_t, (void*)x_t, (void*)rowsq_all, (void*)rowsq_out_all}) if (p) (void)hipFree(p);
+    };
+#define DBG_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return rt_fail(ctx, rt_hip_status(_e), "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    DBG_HIP(hipMalloc((void**)&w16, packed16_bytes(N, K)));
+    DBG_HIP(hipMalloc((void**)&a_t, (size_t)rows * K * 2));
+    DBG_HIP(hipMemsetAsync(a_t, 0, (size_t)rows * K * 2, ctx->stream));
+    PackedW pw;
+    pw.N = N; pw.K = K;
+    rc = launch_pack_weight16(ctx, (const bf16_t*)d_w_bf16, N, K, w16, &pw);
+    const int nb = 256;
+    hipLaunchKernelGGL((k_tile_rows<bf16_t>), dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)d_a_bf16, M, K, row_off, a_t);
+    const int n_part = (N + 15) / 16 * split;                    // RESID: rowsq partials per row
+    ColArgs c;
+    c.A = a_t; c.M = M; c.K = K; c.epi = epi; c.split = split; c.row_off = row_off; c.nt = nt ? 1 : 0; c.eps = eps;
+    c.bias = d_bias; c.scale = d_scale; c.ldc = No;
+    if (d_rowsq) {                                               // rowsq rows are addressed by absolute row (row_off + m)
+        DBG_HIP(hipMalloc((void**)&rowsq_all, (size_t)rows * rowsq_n * 4));
+        DBG_HIP(hipMemsetAsync(rowsq_all, 0, (size_t)rows * rowsq_n * 4, ctx->stream));
+        DBG_HIP(hipMemcpyAsync(rowsq_all + (size_t)row_off * rowsq_n, d_rowsq, (size_t)M * rowsq_n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        c.post_scale = 1; c.rowsq = rowsq_all; c.rowsq_n = rowsq_n;
+    }
+    if (epi == COL_STORE) {
+        c.out = d_x - (size_t)row_off * No;                       // as col_head does: output rows are indexed from row_off
+    } else if (epi == COL_RESID) {
+        DBG_HIP(hipMalloc((void**)&x_t, (size_t)rows * No * 4));
+        DBG_HIP(hipMemsetAsync(x_t, 0, (size_t)rows * No * 4, ctx->stream));
+        hipLaunchKernelGGL((k_tile_rows<float>), dim3(nb), dim3(256), 0, ctx->stream, (const float*)d_x, M, No, row_off, x_t);
+        DBG_HIP(hipMalloc((void**)&rowsq_out_all, (size_t)rows * n_part * 4));
+        DBG_HIP(hipMemsetAsync(rowsq_out_all, 0, (size_t)rows * n_part * 4, ctx->stream));
+        c.out = x_t; c.rowsq_out = rowsq_out_all; c.rowsq_out_n = n_part;
+        if (d_next_bf16) {
+            DBG_HIP(hipMalloc((void**)&next_t, (size_t)rows * No * 2));
+            DBG_HIP(hipMemsetAsync(next_t, 0, (size_t)rows * No * 2, ctx->stream));
+            c.next_bf16 = next_t; c.next_norm_w = d_next_norm_w;
+        }
+    } else {
+        DBG_HIP(hipMalloc((void**)&act_t, (size_t)rows * No * 2));
+        DBG_HIP(hipMemsetAsync(act_t, 0, (size_t)rows * No * 2, ctx->stream));
+        c.out_bf16 = act_t;
+    }
+    const int blk = g_col_rows64 ? 64 : 32;
+    for (int r0 = 0; r0 < M && !rc; r0 += blk) {                 // model.hip col_gemm
+        ColArgs a = c;
+        a.M = std::min(blk, M - r0);
+        a.row_off = row_off + r0;
+        rc = launch_gemm_col(ctx, a, pw);
+    }
+    if (!rc && epi == COL_RESID) {
+        hipLaunchKernelGGL((k_untile_rows<float>), dim3(nb), dim3(256), 0, ctx->stream, (const float*)x_t, M, No, row_off, d_x);
+        if (next_t) hipLaunchKernelGGL((k_untile_rows<bf16_t>), dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)next_t, M, No, row_off, (bf16_t*)d_next_bf16);
+        DBG_HIP(hipMemcpyAsync(d_rowsq_out, rowsq_out_all + (size_t)row_off * n_part, (size_t)M * n_part * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (!rc && epi == COL_SILU)
+        hipLaunchKernelGGL((k_untile_rows<bf16_t>), dim3(nb), dim3(256), 0, ctx->stream, (const bf16_t*)act_t, M, No, row_off, (bf16_t*)d_act_bf16);
+    if (!rc) DBG_HIP(hipGetLastError());
+#undef DBG_HIP
+    cleanup();
+    return rc;
+}
+
+// The decode step's fused attention (q/k-RMSNorm + RoPE + KV append + attention, shared voice-prefix slot) on its own.
+int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim, const float* d_q_norm_w,
+                             const float* d_k_norm_w, float eps, const float* d_cos, const float* d_sin, const int32_t* d_row_slot,
+                             const int32_t* d_row_pos, int32_t pos_add, void* d_k, void* d_v, int32_t slots, int32_t max_pos,
+                             int32_t prefix_slot, int32_t prefix_len, void* d_out_bf16) {
+    if (!ctx || !d_qkv || !d_cos || !d_sin || !d_row_slot || !d_row_pos || !d_k || !d_v || !d_out_bf16 || M < 1)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: null argument");
+    if (prefix_slot >= slots || prefix_len < 0 || prefix_len > max_pos) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: bad prefix");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    KvCache kv;
+    kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
+    kv.prefix_slot = prefix_slot; kv.prefix_len = prefix_slot >= 0 ? prefix_len : 0;
+    const int rc = launch_attention_fused(ctx, d_qkv, M, heads, kv_heads, head_dim, d_q_norm_w, d_k_norm_w, eps, d_cos, d_sin, d_row_slot, d_row_pos,
+                                          pos_add, 0, kv, 0, (bf16_t*)d_out_bf16, nullptr, 0);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
 }

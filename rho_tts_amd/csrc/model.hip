@@ -1062,6 +1062,9 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 mix(ln.b0); mix(ln.n);
             }
         mix(B); mix(col); mix(n_lanes); mix(A->ignore_eos); mix(A->min_frames);
+        // the attention nodes carry the voice prefix (slot, length) by value: a voice of another length must not replay the
+        // old graphs.  The prefix KV *content* is read through pointers, so re-setting a voice of the same length keeps them.
+        mix((uint64_t)Lp); mix((uint64_t)(int64_t)m->talker.kv.prefix_slot);
         for (const rt_sampling* sp : {&A->talker, &A->predictor}) {
             mix(sp->do_sample); mix(sp->top_k);
             uint32_t f;

@@ -366,3 +366,35 @@ def test_batches_above_32_fall_back_to_the_split_k_path(ctx):
             assert float((big - small).abs().max()) <= 0.06 * float(small.std()) + 1e-6
     finally:
         nm.close()
+
+
+def test_voice_switch_does_not_replay_stale_graphs(models):
+    """The decode graphs bake the voice-prefix length into their attention nodes.  After warm generates with voice A, a voice of
+    ANOTHER prefix length decoded with the same batch shape must re-capture: graph replay == eager launches (rt_debug_tune 200),
+    bit for bit, and both match the oracle."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg, nm, om = models
+    greedy = RtSampling(0, 1.0, 1, 1.0, 1.0)
+    va, vb = make_voice(cfg, True, n_ref=9, seed=5), make_voice(cfg, True, n_ref=4, seed=6)
+    na = set_voice(nm, va)
+    for _ in range(3):                                             # graphs captured and replayed for voice A
+        nm.generate(TEXTS, FRAMES, greedy)
+    nb = set_voice(nm, vb)
+    assert na != nb
+    got_graph = nm.generate(TEXTS, FRAMES, greedy)                 # same launch signature as the warm calls but for the prefix length
+    try:
+        nm.lib.rt_debug_tune(200, 0)
+        got_eager = nm.generate(TEXTS, FRAMES, greedy)
+    finally:
+        nm.lib.rt_debug_tune(201, 0)
+    assert all(torch.equal(a, b) for a, b in zip(got_graph, got_eager))
+    tr_o = {}
+    free = om.generate(vb, TEXTS, FRAMES, SamplingParams(), trace=tr_o)
+    _, tr_graph = nm.generate(TEXTS, FRAMES, greedy, forced_codes=free, trace=True)
+    t_o = torch.stack(tr_o["talker_logits"])
+    T, V0 = t_o.shape[0], cfg.codec.codebook_size
+    valid = torch.zeros(T, len(TEXTS), dtype=torch.bool)
+    for b, n in enumerate(FRAMES):
+        valid[:n, b] = True
+    err = (tr_graph["talker"][:T].cpu() - t_o)[valid][:, :V0].abs().max()
+    assert float(err) <= 0.04 * float(t_o[valid][:, :V0].std()), float(err)

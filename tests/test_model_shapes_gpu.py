@@ -1,0 +1,121 @@
+"""Value checks at the shapes bench.py runs (BASELINE.json configs[1] and configs[2]), through the C ABI, against the CPU
+oracle with the bf16 rounding points of a bf16 model (oracle/model.py ``act_bf16``; PARITY UNPINNED against qwen-tts itself,
+which is absent - see the oracle's header):
+
+  C3  Qwen3-TTS-1.7B shapes, batch 32, 30-s reference clone (460-row shared prefix), 10-word sentences
+  C2  Qwen3-TTS-0.6B shapes, batch 8, same prompt
+  codec decoder at the real dimensions (1024-wide pre-transformer, 1536-channel decoder, rates 8/5/4/3), 44 frames
+
+Teacher-forced talker and predictor logits of the first frames must agree to TOL_SIGMA of the logits' standard deviation
+(both sides round activations to bf16 at the same places, so what is left is summation order and the last bit of exp /
+rsqrt; one dropped or misplaced key in the 460-row context moves logits by ~0.2 % of sigma and would fail this).
+Waveform RMSE < 1e-3 is BASELINE.json's stated bar.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle.model import OracleModel, Voice
+from oracle.sampling import SamplingParams
+from rho_tts_amd import config, weights
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(min(32, os.cpu_count() or 8))
+
+TOL_SIGMA = 0.005
+
+WORDS = ("time year people way day man thing woman life child world school state family student group country problem hand part "
+         "place case week company system program question work government number night point home water room mother area").split()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rho_tts_amd import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def clone_voice(cfg, tok, seconds=30.0):
+    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    clip = synthetic_reference_clip(seconds, cfg.sample_rate, 789)
+    ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(75))
+    return conditioning_from_audio(cfg, clip, tok.encode(ref_text), "english", max_frames=cfg.max_positions // 2)
+
+
+def sentences(n, n_words, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [" ".join(WORDS[int(j)] for j in torch.randint(0, len(WORDS), (n_words,), generator=g)).capitalize() + "." for _ in range(n)]
+
+
+@pytest.mark.parametrize("preset,B,n_frames", [("1.7b", 32, 2), ("0.6b", 8, 3)])
+def test_teacher_forced_logits_at_bench_shapes(ctx, preset, B, n_frames):
+    from rho_tts_amd._native_model import NativeModel, RtSampling
+    from rho_tts_amd.tokenizer import HashTokenizer
+    cfg = config.PRESETS[preset]()
+    tok = HashTokenizer(cfg.text_vocab)
+    state = weights.synthetic_state(cfg, 789, device="cuda")
+    nm = NativeModel(ctx, cfg, max_batch=B)
+    try:
+        nm.load_state(state)
+        om = OracleModel(cfg, {k: v.cpu() for k, v in state.items()}, act_bf16=True)
+        del state
+        torch.cuda.empty_cache()
+        cond = clone_voice(cfg, tok)
+        v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
+        n_prefix = nm.set_voice(v.language, None, v.speaker_embed, v.ref_text_ids, v.ref_codes)
+        assert n_prefix == 460                                       # 3 role + 4 control + speaker + bos + 75 words + codec_bos + 375 frames
+        texts = [tok.encode(t) for t in sentences(B, 10, 789)]
+        frames = [n_frames] * B
+        tr_o = {}
+        with torch.no_grad():
+            free = om.generate(v, texts, frames, SamplingParams(), trace=tr_o, share_prefix=True)       # oracle's greedy trajectory
+        codes, tr = nm.generate(texts, frames, RtSampling(0, 1.0, 1, 1.0, 1.0), forced_codes=free, trace=True)
+        assert all(torch.equal(a, b) for a, b in zip(codes, free))
+        V0, G1 = cfg.codec.codebook_size, cfg.n_groups - 1
+        t_o = torch.stack(tr_o["talker_logits"])[..., :V0]                                           # [T, B, V0]
+        t_g = tr["talker"][:n_frames].cpu()[..., :V0]
+        sig = float(t_o.std())
+        e_t = float((t_g - t_o).abs().max()) / sig
+        p_o = torch.stack(tr_o["pred_logits"]).view(n_frames, G1, B, -1)
+        p_g = tr["predictor"][:n_frames].cpu()
+        e_p = float((p_g - p_o).abs().max()) / float(p_o.std())
+        print(f"\\n{cfg.name} B={B}: talker logits err {e_t:.5f} sigma, predictor {e_p:.5f} sigma")
+        assert e_t <= TOL_SIGMA, e_t
+        assert e_p <= TOL_SIGMA, e_p
+        # greedy free-running decode lands on the oracle's codes for the first frame (no compounding yet) almost everywhere
+        got = nm.generate(texts, frames, RtSampling(0, 1.0, 1, 1.0, 1.0))
+        agree = sum(float((a[0] == b[0]).float().mean()) for a, b in zip(got, free)) / B
+        assert agree >= 0.97, agree
+    finally:
+        nm.close()
+
+
+def test_code2wav_at_real_codec_dimensions(ctx):
+    """The codec decoder of the 1.7B / 0.6B presets (they share it): 16 codebooks x 2048, 1024-wide 8-layer pre-transformer
+    (window 72), 2x ConvNeXt upsampling, 1536-channel decoder with rates 8/5/4/3 - 44 frames as in bench.py, and a shorter item
+    beside it in the same launch.  RMSE < 1e-3 against the float32 oracle."""
+    from rho_tts_amd._native_model import NativeModel
+    cfg = config.PRESETS["0.6b"]()
+    state = weights.synthetic_state(cfg, 789, device="cuda")
+    nm = NativeModel(ctx, cfg, max_batch=2, max_positions=256)
+    try:
+        nm.load_state(state)
+        om = OracleModel(cfg, {k: v.cpu() for k, v in state.items() if k.startswith("codec.")})
+        del state
+        torch.cuda.empty_cache()
+        g = torch.Generator().manual_seed(9)
+        Q = cfg.codec.num_quantizers
+        codes = [torch.randint(0, cfg.codec.codebook_size, (n, Q), generator=g) for n in (44, 29)]
+        wavs = nm.code2wav(codes)
+        for c, w in zip(codes, wavs):
+            with torch.no_grad():
+                ref = om.code2wav(c.T[None])[0]
+            assert w.shape[0] == ref.shape[0] == nm.wav_length(c.shape[0])
+            rmse = float(torch.sqrt(torch.mean((w.cpu() - ref) ** 2)))
+            print(f"\\ncode2wav {c.shape[0]} frames: rmse {rmse:.2e}, ref rms {float(ref.pow(2).mean().sqrt()):.3f}")
+            assert rmse < 1e-3, rmse
+            assert float(ref.abs().max()) > 0.05
+    finally:
+        nm.close()

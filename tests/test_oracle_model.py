@@ -198,7 +198,7 @@ def test_predictor_recurrence_matches_transformers_sibling(tiny_model):
     past = torch.randn(B, cfg.talker.hidden, generator=gen) * 0.5
     c0 = torch.randint(0, cfg.codec.codebook_size, (B,), generator=gen)
     trace = {}
-    codes = m.predictor_frame(past, c0, SamplingParams(), 0, list(range(B)), 0, trace=trace)      # greedy
+    codes = m.predictor_frame(None, c0, SamplingParams(), 0, list(range(B)), 0, trace=trace, past_hidden=past)      # greedy
     with torch.no_grad():
         x = torch.stack([proj(past), proj(m.codec_embed(c0))], dim=1)
         out = sib(inputs_embeds=x, past_key_values=DynamicCache(config=hc), use_cache=True)
@@ -211,3 +211,51 @@ def test_predictor_recurrence_matches_transformers_sibling(tiny_model):
     for g in range(G - 1):
         assert float((trace["pred_logits"][g] - ref_logits[g]).abs().max()) < 5e-5, g
     assert torch.equal(codes[:, 1:], torch.stack(ref_codes, 1))
+
+
+def test_shared_prefix_fast_path_equals_full_prompt_forward(tiny_model):
+    """share_prefix=True (prefix through the talker once, K/V copied to every item) gives the logits of the plain
+    per-item full-prompt forward: causality makes them the same numbers up to matmul summation order."""
+    from oracle.model import Voice
+    from oracle.sampling import SamplingParams
+    cfg, m = tiny_model
+    g = torch.Generator().manual_seed(4)
+    v = Voice("english", speaker_embed=torch.randn(cfg.talker.hidden, generator=g) * 0.05, ref_text_ids=[5, 6, 7],
+              ref_codes=torch.randint(0, cfg.codec.codebook_size, (11, cfg.n_groups), generator=g))
+    texts, frames = [[10, 11, 12], [20, 21, 22, 23, 24, 25], [30]], [4, 3, 4]
+    tr_a, tr_b = {}, {}
+    a = m.generate(v, texts, frames, SamplingParams(), trace=tr_a)
+    b = m.generate(v, texts, frames, SamplingParams(), forced_codes=a, trace=tr_b, share_prefix=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    G1 = cfg.n_groups - 1
+    for key, per_frame in (("talker_logits", 1), ("pred_logits", G1)):
+        for i, (x, y) in enumerate(zip(tr_a[key], tr_b[key])):
+            live = torch.tensor([i // per_frame < n for n in frames])      # a finished item's later rows are don't-cares
+            assert float((x - y)[live].abs().max()) < 2e-5 * max(1.0, float(x.abs().max()))
+
+
+def test_bf16_activation_mode_stays_close_to_f32_and_rounds_where_stated():
+    """act_bf16=True follows the same graph with bf16 rounding at GEMM inputs / KV cache: logits move by a few % of sigma
+    (the size of the bound the f32 oracle needed against the GPU), never more; the cached K/V are bf16 values."""
+    from oracle.model import Voice, bf16_round, normed_matmul
+    from oracle.sampling import SamplingParams
+    cfg = config.tiny()
+    state = weights.synthetic_state(cfg, 789)
+    m32, m16 = OracleModel(cfg, state), OracleModel(cfg, state, act_bf16=True)
+    v = Voice("chinese", speaker="ryan")
+    texts, frames = [[10, 11, 12], [20, 21]], [3, 3]
+    tr32, tr16 = {}, {}
+    free = m32.generate(v, texts, frames, SamplingParams(), trace=tr32)
+    m16.generate(v, texts, frames, SamplingParams(), forced_codes=free, trace=tr16)
+    a, b = torch.stack(tr32["talker_logits"]), torch.stack(tr16["talker_logits"])
+    V0 = cfg.codec.codebook_size
+    err = float((a - b)[..., :V0].abs().max()) / float(a[..., :V0].std())
+    assert 1e-5 < err < 0.06, err
+    for kc in m16.talker.k_cache:
+        assert torch.equal(kc, bf16_round(kc))
+    # decode-style rounding: bf16(w * x), row scale on the product
+    x, w = torch.randn(3, 64), 1.0 + 0.1 * torch.randn(64)
+    W = torch.randn(8, 64)
+    got = normed_matmul(x, w, 1e-6, [W], "decode")[0]
+    want = (bf16_round(w * x) @ W.T) * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    assert torch.equal(got, want)

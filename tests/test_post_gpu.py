@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 TOL = 2e-6
 P = O.PostParams()
-LEAVES = ["k1", "noise_burst", "short_loud", "tiny", "all_zero", "quiet", "ragged", "loud_to_end"]
+# edge_thresh: every interior frame sits within an ulp of the -50 dB threshold (x = thr exactly): the reference recorded
+# "frame 1 onwards is above" (start 120, no end trim), which is also what correctly rounded f32 arithmetic gives
+LEAVES = ["k1", "noise_burst", "short_loud", "tiny", "all_zero", "quiet", "edge_thresh", "ragged", "loud_to_end"]
 JOINS = ["k3_2", "k3_3", "mixed_5", "short_mid", "tiny_overlap", "silent_mid"]
 LOUD = ["k4", "k5", "gap", "rising", "exact_2w", "just_over", "hot", "near_silent"]
 
