@@ -217,3 +217,52 @@ def test_fused_attention_matches_fp32(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo
     mask = torch.ones(slots, max_pos, dtype=torch.bool)
     mask[slot.long(), pos.long()] = False
     assert torch.equal(k_new.transpose(1, 2)[mask], kc.transpose(1, 2)[mask]) and torch.equal(v_new.transpose(1, 2)[mask], vc.transpose(1, 2)[mask])
+
+
+@pytest.mark.parametrize("d,heads,kvh,max_pos,M,Lp,pos_lo,pos_hi", [
+    (128, 16, 8, 1024, 32, 460, 461, 540),     # C3 talker step: 16 waves, shared 460-row prefix
+    (128, 16, 8, 1024, 32, 0, 0, 300),         # no prefix
+    (128, 16, 8, 17, 32, 0, 1, 16),            # predictor passes: 4 waves
+    (64, 4, 4, 512, 6, 130, 130, 400),         # head_dim 64 (two cache rows per 128-B line)
+    (32, 4, 1, 256, 4, 9, 9, 200),             # REP 4
+])
+def test_fused_attention_key_census(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo, pos_hi):
+    """EXACT check of WHICH cache rows the fused decode attention reads.  With q = 0 every score is 0 and the softmax is
+    uniform, so the output is the plain mean of the V rows in the context.  V[p] is the indicator of p mod d, hence output
+    dim j is (number of context positions congruent to j) / (pos + 1): a dropped, duplicated or misplaced row (own slot
+    instead of the prefix slot, a row past `pos`, a stale copy of the appended row) changes an integer count and shows up
+    bit for bit - which a tolerance on random data cannot see (one key in 500 moves the output by 0.2 %)."""
+    g = torch.Generator().manual_seed(7)
+    slots = M + 1
+    pslot = M if Lp > 0 else -1
+    width = (heads + 2 * kvh) * d
+    POISON = 64.0
+    pos = torch.randint(pos_lo, pos_hi + 1, (M,), generator=g).to(torch.int32)
+    pos[0], pos[-1] = pos_lo, pos_hi
+    onehot = torch.eye(d)[torch.arange(max_pos) % d]                        # [max_pos, d]
+    vc = torch.full((slots, kvh, max_pos, d), POISON)
+    for r in range(M):
+        vc[r, :, Lp: int(pos[r])] = onehot[Lp: int(pos[r])]                 # own rows [Lp, pos); row `pos` is appended by the launch
+    if pslot >= 0:
+        vc[pslot, :, :Lp] = onehot[:Lp]                                     # the shared prefix lives in its slot only
+    kc = torch.randn(slots, kvh, max_pos, d, generator=g)
+    qkv = torch.zeros(M, width)
+    qkv[:, heads * d: (heads + kvh) * d] = torch.randn(M, kvh * d, generator=g)
+    qkv[:, (heads + kvh) * d:] = onehot[pos.long()].repeat(1, kvh)
+    inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous().cuda(), fr.sin().contiguous().cuda()
+    kd, vd = kc.to(torch.bfloat16).cuda(), vc.to(torch.bfloat16).cuda()
+    out = torch.zeros(M, heads * d, dtype=torch.bfloat16, device="cuda")
+    ones = torch.ones(d).cuda()
+    qkv_d, slot_d, pos_d = qkv.cuda(), torch.arange(M, dtype=torch.int32).cuda(), pos.cuda()
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.rt_debug_attention_fused(ctx.handle, ptr(qkv_d), M, heads, kvh, d, ptr(ones), ptr(ones), 1e-6, ptr(cos), ptr(sin), ptr(slot_d),
+                                               ptr(pos_d), 0, ptr(kd), ptr(vd), slots, max_pos, pslot, Lp, ptr(out)), "rt_debug_attention_fused")
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(M, heads, d)
+    for r in range(M):
+        n = int(pos[r]) + 1
+        count = onehot[:n].sum(0)
+        want = (count / float(n)).to(torch.bfloat16).float()
+        assert torch.equal(got[r], want[None].expand(heads, d)), (r, n, (got[r] - want).abs().max())
