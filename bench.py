@@ -15,6 +15,16 @@ weights are seeded random of the named architecture (no checkpoints offline).
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank
 decodes its own 32 texts; rank 0 computes the voice prefix and broadcasts its KV blob, and the
 finished waveforms are gathered to rank 0, both inside the timed step.
+
+`--corpus N` switches to BASELINE.json configs[3] (C4): ONE corpus of N ragged texts (seed 789,
+U{6..24} words) for the whole job — strong scaling.  The corpus is dealt over the ranks by
+estimated frames (dist.shard_items), every rank buckets its share into batches of `--batch`
+by length (dist.bucket_batches), decodes, post-processes, and the waveforms are gathered to rank 0
+and put back in corpus order (dist.unshard).  The line then also reports the padding efficiency
+sum(frames) / sum(batch max x batch size) of the cut.
+
+`value` counts DELIVERED audio: the samples of the post-processed waveforms the caller receives
+(after silence trim), not the vocoder's raw output.
 """
 from __future__ import annotations
 
@@ -69,6 +79,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--corpus", type=int, default=0, help="C4: one corpus of this many ragged texts for the whole job (strong scaling)")
     ap.add_argument("--tune", default="", help="comma-separated rt_debug_tune codes (100/101 legacy/column decode, 200/201 eager/graph)")
     args = ap.parse_args()
 
@@ -93,7 +104,7 @@ def main():
     from rho_tts_amd import _native, config
     from rho_tts_amd.engine import Engine
     from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
-    from rho_tts_amd.dist import broadcast_voice, gather_waveforms
+    from rho_tts_amd.dist import broadcast_voice, gather_waveforms, padding_efficiency, plan_corpus, unshard
 
     cfg = config.PRESETS[args.model]()
     log(f"rank {rank}/{world}: building {cfg.name} engine (synthetic weights) ...")
@@ -103,24 +114,39 @@ def main():
     for code in [c for c in args.tune.split(",") if c]:
         eng.ctx.lib.rt_debug_tune(int(code), 0)
     B = args.batch
-    texts = sentences(B, args.words, seed=789 + rank)
-    item_ids = list(range(rank * B, (rank + 1) * B))
     ref_words = 75 if args.ref_seconds >= 10 else max(3, int(args.ref_seconds * 2.5))
     clip = synthetic_reference_clip(args.ref_seconds, cfg.sample_rate, 789)
     ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(ref_words))
     cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(ref_text), "english", max_frames=eng.model.max_positions // 2)
     post = _native.make_post_params(sample_rate=cfg.sample_rate, stages=_native.POST_PIPELINE)
+    corpus = None
+    if args.corpus > 0:
+        # C4: the same corpus on every rank (same seed), dealt by estimated frames; item ids = corpus indices, so a text's
+        # audio does not depend on the number of ranks or on the batch it lands in
+        corpus = sentences(args.corpus, (6, 24), seed=789)
+        c_frames = [eng.frames_for(t, 0) for t in corpus]
+        shards, plans = plan_corpus(c_frames, world, B)
+        texts = [corpus[i] for i in shards[rank]]
+        item_ids = list(shards[rank])
+        my_frames = [c_frames[i] for i in shards[rank]]
+        pad_eff = padding_efficiency(c_frames, [b for pl in plans for b in pl])
+    else:
+        texts = sentences(B, args.words, seed=789 + rank)
+        item_ids = list(range(rank * B, (rank + 1) * B))
+        my_frames = None
 
     def step():
         if dist is None or rank == 0:
             eng.set_voice(cond)                                   # conditioning: voice-prefix prefill, once per step
         if dist is not None:
             broadcast_voice(eng, dist, src=0, comm_device=comm_dev)
-        raw = eng.synthesize(texts, seed=789, item_ids=item_ids)
-        outs, stats = eng.post_process([[w] for w in raw], post)
-        audio_s = sum(w.numel() for w in raw) / cfg.sample_rate
+        raw = eng.synthesize(texts, seed=789, item_ids=item_ids, max_frames=my_frames) if texts else []
+        outs, stats = eng.post_process([[w] for w in raw], post) if raw else ([], [])
+        audio_s = sum(o.numel() for o in outs) / cfg.sample_rate   # delivered (post-processed) samples
         if dist is not None:
             host = gather_waveforms(outs, dist, dst=0, device=comm_dev)
+            if corpus is not None and rank == 0:
+                host = unshard(host, shards, len(corpus))
         else:
             host = [o.cpu() for o in outs]
         return audio_s, host
@@ -143,6 +169,8 @@ def main():
         a, _host = step()
         audio_local += a
     sync()
+    if corpus is not None and rank == 0:
+        assert len(_host) == len(corpus) and all(w is not None and w.numel() > 0 for w in _host), "corpus: a waveform is missing"
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     t = torch.tensor([dt, audio_local], dtype=torch.float64, device=comm_dev)
@@ -182,10 +210,13 @@ def main():
         w_talker = 2 * (t_.weight_params() + t_.hidden * cfg.codec_vocab)
         w_pred = 2 * (p_.weight_params() + (cfg.n_groups - 1) * p_.hidden * cfg.predictor_vocab
                       + (t_.hidden * p_.hidden if cfg.has_mtp_proj else 0))
-        frames = eng.frames_for(texts[0], 0)
+        frames = eng.frames_for(texts[0], 0) if corpus is None else int(round(sum(c_frames) / len(c_frames)))
         ctx_len = eng.model.prefix_len() + args.words + 3 + frames // 2
         kv = B * ctx_len * t_.layers * 2 * t_.kv_heads * t_.head_dim * 2
         extra = {"bytes_per_frame": int(w_talker + w_pred + kv), "frames_per_item": frames, "prefix_rows": eng.model.prefix_len()}
+    if corpus is not None:
+        extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(c_frames)), "padding_efficiency": round(pad_eff, 4),
+                      "batches_per_rank": [len(pl) for pl in plans]})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -201,13 +232,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if corpus is None else "strong",
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{cfg.name} bf16, batch {B}/GPU, {args.ref_seconds:g}-s reference clone, {args.words}-word sentences "
-                                   f"({eng.frames_for(texts[0], 0)} frames each), sampling={'greedy' if args.greedy else 'top-k 50 T 0.9'}, "
-                                   "seeded synthetic weights", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "config": {"workload": (f"{cfg.name} bf16, batch {B}/GPU, {args.ref_seconds:g}-s reference clone, "
+                                    + (f"{args.words}-word sentences ({eng.frames_for(texts[0], 0)} frames each)" if corpus is None else
+                                       f"ONE corpus of {len(corpus)} texts of 6-24 words ({min(c_frames)}-{max(c_frames)} frames) sharded by length over the ranks, "
+                                       f"length-bucketed batches")
+                                    + f", sampling={'greedy' if args.greedy else 'top-k 50 T 0.9'}, seeded synthetic weights; "
+                                    "value counts delivered (post-processed) audio"),
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,

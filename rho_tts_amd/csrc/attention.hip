@@ -13,14 +13,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
 // FUSED (decode rows only, one row per sequence slot): `q` is the raw qkv projection [M][(heads+2kv)*D]; the workgroup
 // first finishes its own head group - RMSNorm over the head, rotate-half RoPE, K/V rounded to bf16 and appended to
 // the cache row (slot, pos) - then attends over the cache including the row it has just written.
-template <int D, int REP, bool FUSED, int NW>
+// LO (codec pre-transformer, which has to stay float32-faithful for the waveform RMSE bar): the cache holds K/V as hi + lo
+// bf16 planes (value = hi + lo, ~16 mantissa bits) and the output is written in float32.
+template <int D, int REP, bool FUSED, int NW, bool LO = false>
 __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__ q, int heads, int kv_heads,
                                                    const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
                                                    int pos_add, int window, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
                                                    int max_pos, bf16_t* __restrict__ out, const float* __restrict__ qw,
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
                                                    const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled, int prefix_slot,
-                                                   int prefix_len) {
+                                                   int prefix_len, const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vc_lo,
+                                                   float* __restrict__ out_f32) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     const int64_t pdelta = prefix_slot >= 0 ? (((int64_t)prefix_slot - slot) * kv_heads * max_pos) * D : 0;
     constexpr int STEP = NW * PPW;    // positions the workgroup covers per load slot
     u4_t kk[U], vv[U];
+    u4_t kl[LO ? U : 1], vl[LO ? U : 1];
     auto load_batch = [&](int p0, int last) {      // positions p0 + u * STEP, clamped to [0, last]
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -54,6 +58,10 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
             const int64_t po = (int64_t)pc * D + (pc < prefix_len ? pdelta : 0);
             kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
             vv[u] = *reinterpret_cast<const u4_t*>(vb + po);
+            if (LO) {
+                kl[LO ? u : 0] = *reinterpret_cast<const u4_t*>(kc_lo + base * D + sub * 8 + po);
+                vl[LO ? u : 0] = *reinterpret_cast<const u4_t*>(vc_lo + base * D + sub * 8 + po);
+            }
         }
     };
     const int p_first = lo + w * PPW + pg;
@@ -147,6 +155,12 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 kf[2 * j + 1] = __uint_as_float(kk[u][j] & 0xffff0000u);
                 vf[2 * j] = __uint_as_float(vv[u][j] << 16);
                 vf[2 * j + 1] = __uint_as_float(vv[u][j] & 0xffff0000u);
+                if (LO) {
+                    kf[2 * j] += __uint_as_float(kl[LO ? u : 0][j] << 16);
+                    kf[2 * j + 1] += __uint_as_float(kl[LO ? u : 0][j] & 0xffff0000u);
+                    vf[2 * j] += __uint_as_float(vl[LO ? u : 0][j] << 16);
+                    vf[2 * j + 1] += __uint_as_float(vl[LO ? u : 0][j] & 0xffff0000u);
+                }
             }
 #pragma unroll
             for (int r = 0; r < REP; ++r) {
@@ -202,19 +216,21 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
         }
         const int kcol = (kh * REP + r) * D + sb * 8 + j;
         const int64_t oo = out_tiled ? tile_off(row, kcol, heads * D) : (int64_t)row * heads * D + kcol;
-        out[oo] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
+        if (LO) out_f32[(int64_t)row * heads * D + kcol] = lt > 0.f ? at / lt : 0.f;
+        else out[oo] = f32_to_bf16(lt > 0.f ? at / lt : 0.f);
     }
 }
 
-struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len; };
+struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len;
+                   const bf16_t *kc_lo = nullptr, *vc_lo = nullptr; float* out_f32 = nullptr; };
 
-template <int D, bool FUSED, int NW>
+template <int D, bool FUSED, int NW, bool LO = false>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -233,6 +249,17 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
     bf16_t* kc = kv.k + layer * kv.layer_stride();
     bf16_t* vc = kv.v + layer * kv.layer_stride();
     dim3 grid(kv_heads, M);
+    if (kv.k_lo) {      // hi + lo planes, float32 output: the codec pre-transformer (many rows, short windows: 4 waves)
+        if (FUSED || !f.out_f32 || !kv.v_lo) return rt_fail(ctx, RT_ERR_INVALID, "attention: hi/lo cache needs the unfused form and a float32 output");
+        f.kc_lo = kv.k_lo + layer * kv.layer_stride();
+        f.vc_lo = kv.v_lo + layer * kv.layer_stride();
+        switch (head_dim) {
+            case 32: return dispatch_rep<32, false, 4, true>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+            case 64: return dispatch_rep<64, false, 4, true>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+            case 128: return dispatch_rep<128, false, 4, true>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f);
+            default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: head_dim %d unsupported (32, 64, 128)", head_dim);
+        }
+    }
     // few rows with long contexts (the talker's decode step over a long KV row): 16 waves split the positions;
     // many rows or short contexts (prefill, predictor, sliding window): 4 waves are plenty
     const bool wide = M * kv_heads <= 512 && kv.max_pos > 64 && (window <= 0 || window > 256);
@@ -251,10 +278,12 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
 }  // namespace
 
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
-                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled) {
+                     const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled,
+                     float* out_f32) {
     FusedArgs f{};
     f.frame_ptr = frame_ptr;
     f.out_tiled = out_tiled;
+    f.out_f32 = out_f32;
     return attention_any<false>(ctx, q, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }
 
@@ -262,6 +291,6 @@ int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int 
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
                            const int32_t* frame_ptr, int out_tiled) {
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0};
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

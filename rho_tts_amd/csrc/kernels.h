@@ -142,7 +142,7 @@ int launch_norm_tiled_rows(rt_ctx* ctx, const float* x_tiled, const float* rowsq
 int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, int n_slabs, const float* slab_bias,
                        const float* scale, const float* w, float eps, bf16_t* out_bf16, float* out_f32);
 // act[M][I] = silu(g) * u with g = sum_s slab[s][m][0:I], u = sum_s slab[s][m][I:2I]  -> bf16
-int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out);
+int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out, float* out_f32 = nullptr);
 // y[M][N] = sum_s slab[s] (+ bias), optionally activation, to f32 and/or bf16
 int launch_reduce_slabs(rt_ctx* ctx, const float* slabs, int n_slabs, int64_t M, int N, const float* bias, int act,
                         float* out_f32, bf16_t* out_bf16);
@@ -151,6 +151,10 @@ struct KvCache {
     bf16_t* k = nullptr;   // [layers][slots][kv_heads][max_pos][head_dim]
     bf16_t* v = nullptr;
     int layers = 0, slots = 0, kv_heads = 0, max_pos = 0, head_dim = 0;
+    // Optional low planes (same layout): the cached value is k + k_lo, ~f32 precision.  Only the codec pre-transformer keeps
+    // them - its output feeds the waveform, whose RMSE bar (1e-3) plain bf16 K/V alone would already spend.
+    bf16_t* k_lo = nullptr;
+    bf16_t* v_lo = nullptr;
     // Shared voice prefix: cache rows [0, prefix_len) of EVERY sequence are read from slot `prefix_slot` (one copy in HBM,
     // served from L2 / Infinity Cache to all the workgroups that re-read it) instead of a per-sequence copy.  -1 = off.
     int prefix_slot = -1, prefix_len = 0;
@@ -164,7 +168,7 @@ int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int hea
 // o[M][heads*d] (bf16) = softmax(q k^T / sqrt(d)) v over cache rows [max(0,pos-window+1), pos] of the row's slot
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
                      const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                     const int32_t* frame_ptr = nullptr, int out_tiled = 0);
+                     const int32_t* frame_ptr = nullptr, int out_tiled = 0, float* out_f32 = nullptr);
 
 // Every launch that depends on the frame index takes `frame_ptr` (device int, nullptr = 0): positions are
 // row_pos + pos_add + *frame_ptr, so one captured hipGraph serves every frame of the decode loop.

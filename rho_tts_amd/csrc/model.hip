@@ -239,7 +239,7 @@ const PackedW& PW(rt_model* m, const std::string& n) { return find_slot(m, n)->p
 float* VEC(rt_model* m, const std::string& n) { Slot* s = find_slot(m, n); return s ? s->vec : nullptr; }
 bf16_t* TBL(rt_model* m, const std::string& n) { return find_slot(m, n)->tbl; }
 
-int bind_stack(rt_model* m, StackW& S, const char* p, const rt_stack_dims& d, int slots, int max_pos, int window) {
+int bind_stack(rt_model* m, StackW& S, const char* p, const rt_stack_dims& d, int slots, int max_pos, int window, bool lo_planes = false) {
     S.d = d;
     S.window = window;
     S.L.resize(d.layers);
@@ -258,6 +258,12 @@ int bind_stack(rt_model* m, StackW& S, const char* p, const rt_stack_dims& d, in
     RT_HIP(m->ctx, hipMalloc((void**)&S.kv.v, bytes));
     RT_HIP(m->ctx, hipMemsetAsync(S.kv.k, 0, bytes, m->ctx->stream));
     RT_HIP(m->ctx, hipMemsetAsync(S.kv.v, 0, bytes, m->ctx->stream));
+    if (lo_planes) {
+        RT_HIP(m->ctx, hipMalloc((void**)&S.kv.k_lo, bytes));
+        RT_HIP(m->ctx, hipMalloc((void**)&S.kv.v_lo, bytes));
+        RT_HIP(m->ctx, hipMemsetAsync(S.kv.k_lo, 0, bytes, m->ctx->stream));
+        RT_HIP(m->ctx, hipMemsetAsync(S.kv.v_lo, 0, bytes, m->ctx->stream));
+    }
     return RT_OK;
 }
 
@@ -300,7 +306,23 @@ int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* s
     return RT_OK;
 }
 
+// float32 rows (fed as hi + lo bf16 planes, split on load) times W^T -> raw f32 slabs: the float32-faithful form of gemm_rows
+int gemm_rows_f32(rt_model* m, const float* A, int rows, const PackedW& W, float* slabs, int* n_slabs) {
+    const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);
+    int S = 1;
+    // (slab workspace: 8 slabs for > 64 rows, 64 x 32768 floats otherwise - slab_floats)
+    while (S < 8 && tiles * S < g_prefill_fill * m->ctx->n_cu && W.K / (S * 2) >= 256 && (rows > 64 || (int64_t)S * 2 * W.N <= 32768)) S *= 2;
+    GemmA a; a.ptr = A; a.is_f32 = 1; a.split = 1; a.M = rows; a.Cin = W.K; a.taps = 1;
+    GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = S;
+    RT_TRY(launch_gemm(m->ctx, a, W, e));
+    *n_slabs = S;
+    return RT_OK;
+}
+
 struct StackWs {
+    float* xn32 = nullptr;    // precise stacks: float32 operands [M][H], [M][q_dim], [M][I]
+    float* ao32 = nullptr;
+    float* act32 = nullptr;
     bf16_t* xn = nullptr;     // [M][H]
     float* slabs = nullptr;   // max over GEMMs
     float* q = nullptr;       // [M][q_dim]
@@ -311,7 +333,15 @@ size_t slab_floats(const rt_stack_dims& d, int M) {
     const size_t widest = std::max<size_t>((size_t)2 * d.inter, (size_t)(d.heads + 2 * d.kv_heads) * d.head_dim);
     return std::max<size_t>((size_t)M * widest * (M > 64 ? 8 : 1), (size_t)64 * 32768);
 }
-int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w) {
+int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w, bool precise = false) {
+    if (precise) {
+        RT_TRY(pool_arr(m, (size_t)M * d.hidden, &w->xn32));
+        RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->ao32));
+        RT_TRY(pool_arr(m, (size_t)M * d.inter, &w->act32));
+        RT_TRY(pool_arr(m, slab_floats(d, M), &w->slabs));
+        RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
+        return RT_OK;
+    }
     RT_TRY(pool_arr(m, (size_t)M * d.hidden, &w->xn));
     RT_TRY(pool_arr(m, slab_floats(d, M), &w->slabs));
     RT_TRY(pool_arr(m, (size_t)M * d.heads * d.head_dim, &w->q));
@@ -328,6 +358,29 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
     const int H = d.hidden;
     int ns = 0;
     const float* pending_scale = nullptr;
+    if (w.xn32) {
+        // float32-faithful form (codec pre-transformer): every GEMM operand stays float32 and is fed to the MFMAs as hi + lo
+        // bf16 planes, K/V are cached as hi + lo planes, attention and SwiGLU write float32.  Plain bf16 operands here cost
+        // 3.2e-3 of waveform RMSE at the real codec dimensions (8 layers, 1024 wide) - each of the four rounding points
+        // alone >= 1e-3 (tests/test_model_shapes_gpu.py, DESIGN.md "Precision policy") - for 0.2 of the decoder's 5.1 GFLOP/frame.
+        if (!S.kv.k_lo || !out_f32 || out_bf16) return rt_fail(ctx, RT_ERR_STATE, "stack_forward: precise mode needs hi/lo K/V planes and a float32 output");
+        for (int i = 0; i < d.layers; ++i) {
+            LayerW& L = S.L[i];
+            RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, L.ln1, d.rms_eps, nullptr, w.xn32));
+            RT_TRY(gemm_rows_f32(m, w.xn32, M, L.wqkv, w.slabs, &ns));
+            RT_TRY(launch_qkv_post(ctx, w.slabs, ns, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
+                                   pos_add, w.q, S.kv, i, frame_ptr));
+            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, nullptr, frame_ptr, 0, w.ao32));
+            RT_TRY(gemm_rows_f32(m, w.ao32, M, L.wo, w.slabs, &ns));
+            RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, L.ls1, L.ln2, d.rms_eps, nullptr, w.xn32));
+            RT_TRY(gemm_rows_f32(m, w.xn32, M, L.wgu, w.slabs, &ns));
+            RT_TRY(launch_silu_mul(ctx, w.slabs, ns, M, d.inter, nullptr, w.act32));
+            RT_TRY(gemm_rows_f32(m, w.act32, M, L.wd, w.slabs, &ns));
+            pending_scale = L.ls2;
+        }
+        RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, S.norm, d.rms_eps, nullptr, out_f32));
+        return RT_OK;
+    }
     for (int i = 0; i < d.layers; ++i) {
         LayerW& L = S.L[i];
         RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, L.ln1, d.rms_eps, w.xn, nullptr));
@@ -501,6 +554,8 @@ int rt_model_destroy(rt_model* m) {
     for (StackW* S : {&m->talker, &m->pred, &m->ctf}) {
         if (S->kv.k) (void)hipFree(S->kv.k);
         if (S->kv.v) (void)hipFree(S->kv.v);
+        if (S->kv.k_lo) (void)hipFree(S->kv.k_lo);
+        if (S->kv.v_lo) (void)hipFree(S->kv.v_lo);
         if (S->cos) (void)hipFree(S->cos);
         if (S->sin) (void)hipFree(S->sin);
     }
@@ -594,7 +649,7 @@ int rt_model_finalize(rt_model* m, const float* h_rope_cos[3], const float* h_ro
     const rt_model_config& c = m->cfg;
     RT_TRY(bind_stack(m, m->talker, "talker", c.talker, c.max_batch + 1, c.max_positions, 0));
     RT_TRY(bind_stack(m, m->pred, "pred", c.predictor, c.max_batch, c.n_groups + 1, 0));
-    RT_TRY(bind_stack(m, m->ctf, "ctf", c.codec_tf, c.max_batch, c.max_codec_frames, c.codec_sliding_window));
+    RT_TRY(bind_stack(m, m->ctf, "ctf", c.codec_tf, c.max_batch, c.max_codec_frames, c.codec_sliding_window, true));
     StackW* stacks[3] = {&m->talker, &m->pred, &m->ctf};
     for (int i = 0; i < 3; ++i) {
         StackW& S = *stacks[i];
@@ -1221,7 +1276,7 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
     RT_TRY(pool_arr(m, (size_t)rows0 * Hc, &hn));
     {
         StackWs w;
-        RT_TRY(alloc_stack_ws(m, c.codec_tf, (int)rows0, &w));
+        RT_TRY(alloc_stack_ws(m, c.codec_tf, (int)rows0, &w, true));
         RT_TRY(stack_forward(m, m->ctf, w, h, (int)rows0, d_slot, d_pos, 0, nullptr, hn));
     }
     // ---- ConvNeXt upsampling stages (transposed conv k = stride = r is a plain GEMM in channels-last).

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_norm_tiled_rows(const float* __restrict
 }
 
 __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t slab_stride, int I, bf16_t* __restrict__ out,
-                           int64_t total4) {
+                           int64_t total4, float* __restrict__ out_f32) {
     const int I4 = I >> 2;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = idx / I4;
@@ -197,6 +197,7 @@ __global__ void k_silu_mul(const float* __restrict__ slabs, int n_slabs, int64_t
         float r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = g[j] / (1.f + __expf(-g[j])) * u[j];
+        if (out_f32) { reinterpret_cast<f4_t*>(out_f32)[idx] = f4_t{r[0], r[1], r[2], r[3]}; continue; }
         uint2 pk;
         pk.x = (unsigned)f32_to_bf16(r[0]) | ((unsigned)f32_to_bf16(r[1]) << 16);
         pk.y = (unsigned)f32_to_bf16(r[2]) | ((unsigned)f32_to_bf16(r[3]) << 16);
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
                                                  float eps, const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                  const int32_t* __restrict__ row_slot, const int32_t* __restrict__ row_pos,
                                                  int pos_add, float* __restrict__ q_out, bf16_t* __restrict__ kc,
-                                                 bf16_t* __restrict__ vc, int max_pos, const int32_t* __restrict__ frame_ptr) {
+                                                 bf16_t* __restrict__ vc, int max_pos, const int32_t* __restrict__ frame_ptr,
+                                                 bf16_t* __restrict__ kc_lo, bf16_t* __restrict__ vc_lo) {
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int width = (heads + 2 * kv_heads) * d;
     const int half = d >> 1;
@@ -259,9 +261,16 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
         o[lane + half] = b;
     } else {
         const int kh = is_k ? hd - heads : hd - heads - kv_heads;
-        bf16_t* o = (is_k ? kc : vc) + (((int64_t)slot * kv_heads + kh) * max_pos + pos) * d;
-        o[lane] = f32_to_bf16(a);
-        o[lane + half] = f32_to_bf16(b);
+        const int64_t off = (((int64_t)slot * kv_heads + kh) * max_pos + pos) * d;
+        bf16_t* o = (is_k ? kc : vc) + off;
+        const bf16_t ha = f32_to_bf16(a), hb = f32_to_bf16(b);
+        o[lane] = ha;
+        o[lane + half] = hb;
+        if (kc_lo) {                                  // low planes: what the bf16 rounding dropped
+            bf16_t* l = (is_k ? kc_lo : vc_lo) + off;
+            l[lane] = f32_to_bf16(a - bf16_to_f32(ha));
+            l[lane + half] = f32_to_bf16(b - bf16_to_f32(hb));
+        }
     }
 }
 
@@ -440,11 +449,11 @@ int launch_norm_tiled_rows(rt_ctx* ctx, const float* x_tiled, const float* rowsq
     return RT_OK;
 }
 
-int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out) {
+int launch_silu_mul(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int I, bf16_t* out, float* out_f32) {
     const int64_t total = (int64_t)M * I / 4;
     if (total <= 0) return RT_OK;
     if (I % 4) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "silu_mul: intermediate size %d not a multiple of 4", I);
-    hipLaunchKernelGGL(k_silu_mul, dim3(grid_for(total, 64)), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * 2 * I, I, out, total);
+    hipLaunchKernelGGL(k_silu_mul, dim3(grid_for(total, 64)), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * 2 * I, I, out, total, out_f32);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -467,7 +476,8 @@ int launch_qkv_post(rt_ctx* ctx, const float* slabs, int n_slabs, int M, int hea
     const int width = (heads + 2 * kv_heads) * head_dim;
     hipLaunchKernelGGL(k_qkv_post, dim3(M, heads + 2 * kv_heads), dim3(64), 0, ctx->stream, slabs, n_slabs, (int64_t)M * width, heads,
                        kv_heads, head_dim, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, q_out,
-                       kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(), kv.max_pos, frame_ptr);
+                       kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(), kv.max_pos, frame_ptr,
+                       kv.k_lo ? kv.k_lo + layer * kv.layer_stride() : nullptr, kv.v_lo ? kv.v_lo + layer * kv.layer_stride() : nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

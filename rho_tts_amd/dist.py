@@ -28,6 +28,35 @@ def shard_items(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(x) for x in out]
 
 
+def bucket_batches(costs: Sequence[float], batch: int) -> List[List[int]]:
+    """Cut items into batches of ``batch`` indices.  A batch decodes until its longest member ends, so when there is more
+    than one batch the items are bucketed by cost (longest first, ties by index) - each batch then holds items of similar
+    length - and the indices inside a batch stay ascending.  One batch or less: arrival order."""
+    n = len(costs)
+    if n <= batch:
+        return [list(range(n))] if n else []
+    order = sorted(range(n), key=lambda i: (-costs[i], i))
+    return [sorted(order[b0:b0 + batch]) for b0 in range(0, n, batch)]
+
+
+def padding_efficiency(costs: Sequence[float], batches: Sequence[Sequence[int]]) -> float:
+    """Useful row-frames / decoded row-frames = sum(frames) / sum(batch max x batch size)."""
+    padded = sum(max(costs[i] for i in b) * len(b) for b in batches if len(b))
+    return float(sum(costs[i] for b in batches for i in b)) / padded if padded else 1.0
+
+
+def plan_corpus(costs: Sequence[float], world: int, batch: int) -> Tuple[List[List[int]], List[List[List[int]]]]:
+    """The C4 plan: deal the corpus over ``world`` ranks by cost (shard_items), then bucket each rank's share
+    into batches.  Returns (shards, batches): shards[r] = rank r's item indices (ascending), batches[r] = its batches as
+    lists of GLOBAL item indices."""
+    shards = shard_items(costs, world)
+    plans = []
+    for sh in shards:
+        local = bucket_batches([costs[i] for i in sh], batch)
+        plans.append([[sh[k] for k in b] for b in local])
+    return shards, plans
+
+
 def broadcast_voice(engine, dist, src: int = 0, comm_device=None) -> None:
     """Rank ``src`` has computed the voice prefix (Engine.set_voice); every other rank imports its KV blob.
     ``comm_device``: where the collective runs (the GPU for RCCL; "cpu" to rehearse on gloo)."""

@@ -139,16 +139,34 @@ class Engine:
                 out[i] = torch.cat(parts)
         return out  # type: ignore[return-value]
 
+    def plan_batches(self, frames: Sequence[int]) -> List[List[int]]:
+        """Batches of ``max_batch`` text indices.  One batch keeps arrival order; more are bucketed by frame budget, longest
+        first: a batch decodes until its longest member is done, so similar lengths keep its rows busy (dist.bucket_batches)."""
+        from .dist import bucket_batches
+        return bucket_batches(frames, self.max_batch)
+
     def synthesize(self, texts: Sequence[str], seed: int = 789, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
-                   max_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
-        """Raw waveforms (GPU float32, 1-D) for a batch of texts, ``max_batch`` at a time."""
-        wavs: List[torch.Tensor] = []
-        for i0 in range(0, len(texts), self.max_batch):
-            sl = slice(i0, i0 + self.max_batch)
-            ids = list(item_ids[sl]) if item_ids is not None else list(range(i0, min(i0 + self.max_batch, len(texts))))
-            codes = self.generate_codes(texts[sl], seed, ids, cancel_flag, max_frames[sl] if max_frames is not None else None)
-            wavs += self.vocode(codes)
-        return wavs
+                   max_frames: Optional[Sequence[int]] = None, stats: Optional[dict] = None) -> List[torch.Tensor]:
+        """Raw waveforms (GPU float32, 1-D) for a batch of texts, ``max_batch`` at a time, in the order of ``texts``.
+        The RNG stream of a text is its ``item_ids`` entry (default: its index), so the result does not depend on how the
+        texts are cut into batches.  ``stats`` (optional dict) receives the padding efficiency of the cut."""
+        n = len(texts)
+        ids = list(item_ids) if item_ids is not None else list(range(n))
+        if max_frames is not None:
+            frames = [int(f) for f in max_frames]
+        else:
+            frames = [self.frames_for(t, len(self.tokenizer.encode(t))) for t in texts]
+        wavs: List[Optional[torch.Tensor]] = [None] * n
+        batches = self.plan_batches(frames)
+        for idx in batches:
+            codes = self.generate_codes([texts[i] for i in idx], seed, [ids[i] for i in idx], cancel_flag, [frames[i] for i in idx])
+            for i, w in zip(idx, self.vocode(codes)):
+                wavs[i] = w
+        if stats is not None:
+            stats["frames"] = stats.get("frames", 0) + sum(frames)
+            stats["padded_frames"] = stats.get("padded_frames", 0) + sum(max(frames[i] for i in idx) * len(idx) for idx in batches)
+            stats["batches"] = stats.get("batches", 0) + len(batches)
+        return wavs  # type: ignore[return-value]
 
     # ------------------------------------------------------------------ post
     def post_process(self, items: Sequence[Sequence[torch.Tensor]], params: _native.PostParams):

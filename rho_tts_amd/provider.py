@@ -116,8 +116,7 @@ class BatchedPipeline:
             if iteration > 0:
                 self.seed = int(time.time() * 1000) % 100000
             retry: List[int] = []
-            for b0 in range(0, len(todo), bs):
-                chunk = todo[b0:b0 + bs]
+            for chunk in self._cut_batches(todo, work, bs):
                 for w in chunk:
                     i, s, _ = work[w]
                     if token.is_cancelled():
@@ -156,6 +155,22 @@ class BatchedPipeline:
             if best[w] is not None and best_drift[w] != float("inf"):
                 scores[work[w][0]][0].append(best_drift[w])
         return accepted
+
+    def _estimate_cost(self, segment: str) -> Optional[float]:
+        """Expected decode length of a segment (any monotone unit), or None when the provider cannot tell.
+        A batch decodes until its LONGEST member ends, so ragged batches idle their short rows."""
+        return None
+
+    def _cut_batches(self, todo: List[int], work, bs: int) -> List[List[int]]:
+        """Cut the work list into batches of ``bs``.  More work than one batch is bucketed by estimated length (longest first,
+        so every batch holds segments of similar length); fewer keeps arrival order.  The RNG stream of a segment is its index
+        in the work list, so the audio of every segment is the same for any cut; inside a batch the indices stay ascending."""
+        if len(todo) > bs:
+            costs = {w: self._estimate_cost(work[w][2]) for w in todo}
+            if all(c is not None for c in costs.values()):
+                order = sorted(todo, key=lambda w: (-costs[w], w))
+                return [sorted(order[b0:b0 + bs]) for b0 in range(0, len(order), bs)]
+        return [todo[b0:b0 + bs] for b0 in range(0, len(todo), bs)]
 
     def _generate_chunk(self, segs: List[str], item_idx: List[int], token) -> List[Optional[torch.Tensor]]:
         """One batched ``_generate_audio`` call; on failure fall back to one call per segment so that the
@@ -358,6 +373,12 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
         else:
             eng.set_voice_from_audio(self.reference_audio_path, self.reference_text, self.language)
         self._voice_key = key
+
+    def _estimate_cost(self, segment: str) -> Optional[float]:
+        eng = self._engine
+        if eng is not None:
+            return float(eng.frames_for(segment, len(eng.tokenizer.encode(segment))))
+        return float(max(1, len(segment.split())))
 
     # ---------------------------------------------------------------- provider contract
     def _generate_audio(self, text: Union[str, List[str]], **kwargs) -> Union[torch.Tensor, List[torch.Tensor]]:

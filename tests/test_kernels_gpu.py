@@ -78,6 +78,9 @@ def test_split_precision_gemm_is_f32_faithful(ctx):
     e_split = float((gemm(ctx, a, w, split_prec=True).double() - ref).abs().max())
     scale = float(ref.abs().max())
     assert e_split < 2e-5 * scale and e_split * 30 < e_plain, (e_split, e_plain, scale)
+    # ... also with K split over workgroups (the codec pre-transformer's float32-faithful projections at few rows)
+    e_split_k = float((gemm(ctx, a, w, split_prec=True, split_k=3).double() - ref).abs().max())
+    assert e_split_k < 2e-5 * scale, (e_split_k, scale)
     # causal dilated conv in split mode
     x = rnd(2, 100, 32, seed=43)
     wc = rnd(48, 32, 7, scale=0.1, seed=44).to(torch.bfloat16)
