@@ -377,6 +377,7 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
             RT_TRY(launch_silu_mul(ctx, w.slabs, ns, M, d.inter, nullptr, w.act32));
             RT_TRY(gemm_rows_f32(m, w.act32, M, L.wd, w.slabs, &ns));
             pending_scale = L.ls2;
+            if (g_sync_parts && !g_use_graph) RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, S.norm, d.rms_eps, nullptr, out_f32));
         return RT_OK;
@@ -394,6 +395,7 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
         RT_TRY(launch_silu_mul(ctx, w.slabs, ns, M, d.inter, w.act));
         RT_TRY(gemm_rows(m, w.act, M, L.wd, w.slabs, &ns));
         pending_scale = L.ls2;
+        if (g_sync_parts && !g_use_graph) RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (profiling aid: bounds the dispatches in flight)
     }
     RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, pending_scale, S.norm, d.rms_eps, out_bf16, out_f32));
     return RT_OK;
@@ -470,6 +472,7 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
         dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w; dn.split = sp_h;
         RT_TRY(col_gemm(m, dn, L.wd, isp));
+        if (g_sync_parts && !g_use_graph) RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return RT_OK;
 }
@@ -1173,6 +1176,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             ctx->stream = ln.stream;
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l], ln.stream));
             else RT_TRY(enqueue_a(ln));
+            if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
             if (!A->ignore_eos)
                 RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)t * B + ln.b0, d_eos + (size_t)t * B + ln.b0, ln.n * 4, hipMemcpyDeviceToHost, ln.stream));
         }
@@ -1202,6 +1206,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             ctx->stream = ln.stream;
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l + 1], ln.stream));
             else RT_TRY(enqueue_b(ln));
+            if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         }
         ctx->stream = main_stream;
     }

@@ -170,7 +170,16 @@ def synth_tensor(spec: Spec, cfg: ModelConfig, base_seed: int, device="cpu") -> 
 
 
 def synthetic_state(cfg: ModelConfig, seed: int = 789, device="cpu", only_prefix: str = "") -> Dict[str, torch.Tensor]:
-    return {sp[0]: synth_tensor(sp, cfg, seed, device) for sp in tensor_specs(cfg) if sp[0].startswith(only_prefix)}
+    out: Dict[str, torch.Tensor] = {}
+    on_gpu = str(device).startswith("cuda")
+    for sp in tensor_specs(cfg):
+        if sp[0].startswith(only_prefix):
+            out[sp[0]] = synth_tensor(sp, cfg, seed, device)
+            if on_gpu and len(out) % 8 == 0:
+                # ~10 launches per tensor: keep the queue shallow (rocprofv3 --pmc on this image faults once a few hundred
+                # dispatches are queued without a host wait: tools/pmc_probe.py flood / syncflood, profiles/README.md)
+                torch.cuda.synchronize()
+    return out
 
 
 def load_safetensors(cfg: ModelConfig, model_dir: str, device="cpu") -> Dict[str, torch.Tensor]:

@@ -50,6 +50,17 @@ elif variant == "unfused4":
 elif variant == "post":
     x = torch.randn(48000, device="cuda") * 0.1
     ctx.post_process(_native.make_post_params(), [[x]])
+elif variant.startswith("syncflood"):    # the same number of launches, but the host waits for the stream every 400
+    n = int(variant[9:] or 20000)
+    us = C.c_double()
+    lib.rt_bench_launch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    for _ in range(n // 800):
+        ctx.check(lib.rt_bench_launch(ctx.handle, 256, 400, 0, 1, C.byref(us)), "rt_bench_launch")     # (400 warm + 400 timed, each followed by a sync)
+elif variant.startswith("flood"):        # N dependent trivial launches with no host sync in between: how many may be in flight?
+    n = int(variant[5:] or 4000)
+    us = C.c_double()
+    lib.rt_bench_launch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    ctx.check(lib.rt_bench_launch(ctx.handle, 256, n, 0, 1, C.byref(us)), "rt_bench_launch")
 else:
     raise SystemExit("unknown variant")
 ctx.synchronize()
