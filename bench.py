@@ -196,13 +196,20 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_gemm_col", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": None, "launches": int(n_l),
                     "avg_launch_us": round(ms * 1e3 / n_l, 3), "avg_bytes_per_launch": round(by / n_l, 1)}
-            # HBM-side bytes per launch: the PMC pass cannot run inside this process, so the committed FETCH_SIZE measurement
-            # of the same kernel on the same GEMM shapes (profiles/r01_d_pmc_ratio.json) scales the algorithmic bytes
+            # HBM-side bytes per launch: counters cannot be read from inside this process, so `traffic` is the FETCH_SIZE of the
+            # SAME step (same model, batch, prompt and launch sequence) collected by `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py
+            # --steps 1 --warmup 0 --tune 200,1301` and reduced by tools/pmc_step_split.py (x 1024 x 2: KiB, gfx950 correction)
+            default_workload = args.model == "1.7b" and B == 32 and args.words == 10 and args.ref_seconds == 30.0 and corpus is None
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_pmc_ratio.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_bench_step.json")) as f:
                     pmc = json.load(f)
-                roof["traffic"] = round(by / n_l * float(pmc["ratio"]), 1)
-                roof["traffic_source"] = "FETCH_SIZE (x2 gfx950 correction) / algorithmic = %.4f, %s" % (pmc["ratio"], pmc["file"])
+                if default_workload and pmc["k_gemm_col_dispatches"] == int(n_l):
+                    roof["traffic"] = float(pmc["all"]["fetched_bytes_per_dispatch"])
+                    roof["traffic_source"] = ("FETCH_SIZE x 1024 x 2 per k_gemm_col dispatch, counter pass over bench.py itself "
+                                              "(profiles/r02_pmc_fetch_bench_step.json: fetched / algorithmic = %.3f; talker layers %.3f, "
+                                              "predictor layers %.3f - the predictor is Infinity-Cache resident, FETCH_SIZE counts its L2 misses)"
+                                              % (pmc["all"]["fetched_over_algorithmic"], pmc["classes"]["talker layers"]["fetched_over_algorithmic"],
+                                                 pmc["classes"]["predictor layers"]["fetched_over_algorithmic"]))
             except (OSError, KeyError, ValueError):
                 pass
         # decode-step view: algorithmic bytes per frame for the local batch
