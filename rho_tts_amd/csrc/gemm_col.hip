@@ -47,7 +47,11 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 // 1.5x the CUs on the 1.7B talker, and one-per-CU would run them as a full round plus a half-empty one.
 // MT = 16-row sub-blocks per launch: 2 (M <= 32, every single-position decode pass) or 4 (M <= 64: the predictor's first
 // pass carries two positions per sequence; one 64-row launch streams the weights once instead of twice).
-template <int EPI, int MT>
+// NPRE = super-chunks requested up front WITHOUT a branch around them (1 or 2, chosen by the launcher from K; indices are
+// clamped so every request is a valid address).  Branch-free matters: the row-scale partials are requested just before the
+// chunks, and only when the number of younger loads is a compile-time constant can the compiler wait for them with a
+// counted `s_waitcnt vmcnt(N)` instead of draining the weight chunks too.  NPRE = 0 keeps the fully guarded form (any K).
+template <int EPI, int MT, int NPRE>
 __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_gemm_col(ColArgs g) {
     __shared__ float red[WAVES][MT][4][64];  // 16 KiB per 32 rows: one 16x16 accumulator tile per sub-block and wave
     __shared__ float sh_inv[16 * MT];        // RMSNorm row scales
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
 #pragma unroll
         for (int u = 0; u < C; ++u) {
             int k = sc * C + u;
-            if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile, its product is skipped
+            if (k >= n_k) k = n_k - 1;                // tail: re-load the last tile (an L1 / L2 hit), its product is skipped
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const s8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -100,33 +104,65 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
     };
 
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[0] = wall_clock64();
-    Chunk c0, c1;
-    if (n_sc > 0) issue(0, c0);
+    // The small operands of the prologue / epilogue are requested FIRST: vector-memory loads return in issue order, so anything
+    // issued behind the 16 KiB weight / activation chunks would only arrive after them - the RMSNorm row scales used to cost
+    // every NORM launch 1-1.5 us that way (in-kernel stamps, tools/bench_gemm_col.py), and the epilogue's per-column vectors a
+    // dependent L2 round trip after the reduce.
     // the output elements this thread finishes in the epilogue: pass ps -> sub-block 2 ps + (tid >> 8), accumulator register i, lane l
     const int e_i = (tid >> 6) & 3, e_l = tid & 63;
     const int n = nt * 16 + (e_l & 15);
     const bool e_mine = ((e_l & 15) >> cw_shift) == sub;
-    float xres[PASSES];
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-        const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
-        xres[ps] = 0.f;
-        if (EPI == COL_RESID && e_row < g.M && n < g.N && e_mine) xres[ps] = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
-    }
+    const bool n_ok = n < g.N && e_mine;
+    float rq[PASSES][16];                      // rowsq partials of rows 32 ps + 4 w + qd, 16 per lane (<= 256 partials per row)
+    constexpr int RQ_MAX = 256;
     if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns rows 4w + qd (+ 32 per pass), its lanes split the partials
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row_i = 32 * ps + 4 * w + qd;
             const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
             const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int j = r + 16 * it;
+                rq[ps][it] = p[j < g.rowsq_n ? j : g.rowsq_n - 1];          // (unconditional request, see NPRE; masked when summed)
+            }
+        }
+    }
+    float xres[PASSES];
+    float e_bias = 0.f, e_scale = 1.f, e_nw = 0.f;
+    if (n_ok) {
+        if (EPI != COL_SILU && g.bias) e_bias = g.bias[n];
+        if (EPI == COL_RESID && g.scale) e_scale = g.scale[n];
+        if (EPI == COL_RESID && g.next_bf16) e_nw = g.next_norm_w[n];
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
+        xres[ps] = 0.f;
+        if (EPI == COL_RESID && e_row < g.M && n_ok) xres[ps] = g.out[tile_off(g.row_off + e_row, n, (int)g.ldc)];
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the small requests ahead of the chunks ...
+    Chunk c0, c1;
+    if (NPRE >= 1 || n_sc > 0) issue(0, c0);
+    if (NPRE >= 2 || (NPRE == 0 && n_sc > 1)) issue(1, c1);
+    __builtin_amdgcn_sched_barrier(0);          // ... and their consumers behind them (the scheduler would hoist the row-scale sums)
+    if (g.post_scale) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row_i = 32 * ps + 4 * w + qd;
             float s = 0.f;
-            for (int j = r; j < g.rowsq_n; j += 16) s += p[j];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) s += (r + 16 * it < g.rowsq_n) ? rq[ps][it] : 0.f;
+            if (g.rowsq_n > RQ_MAX) {             // (more partials than the unrolled window: not a shape the model produces)
+                const int row = g.row_off + (row_i < g.M ? row_i : g.M - 1);
+                const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
+                for (int j = RQ_MAX + r; j < g.rowsq_n; j += 16) s += p[j];
+            }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
         }
     }
-    if (n_sc > 1) issue(1, c1);
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[1] = wall_clock64();
 
     f4acc_t acc[NB][MT];
@@ -182,23 +218,23 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
-        const bool ok = e_row < g.M && n < g.N && e_mine;
+        const bool ok = e_row < g.M && n_ok;
         const float inv = g.post_scale ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
         float v = val[0][ps] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
-                if (g.bias) v += g.bias[n];
+                v += e_bias;
                 g.out[(int64_t)(g.row_off + e_row) * g.ldc + n] = v;    // STORE outputs (qkv, logits, mtp rows) stay row-major
             }
         } else if (EPI == COL_RESID) {
             float xn = 0.f;
             if (ok) {
-                if (g.bias) v += g.bias[n];
-                if (g.scale) v *= g.scale[n];
+                v += e_bias;
+                v *= e_scale;
                 xn = xres[ps] + v;
                 const int64_t o = tile_off(g.row_off + e_row, n, (int)g.ldc);
                 g.out[o] = xn;
-                if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(g.next_norm_w[n] * xn);   // operand of the GEMM behind the next RMSNorm
+                if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(e_nw * xn);   // operand of the GEMM behind the next RMSNorm
             }
             float sq = xn * xn;                   // a 16-lane group = one row's 16 columns
 #pragma unroll
@@ -214,18 +250,30 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int NPRE>
 void launch_one(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
-    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
-    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
+    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
+    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
+}
+
+template <int EPI, int MT>
+void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
+    // every wave needs at least one k-tile for the clamped (branch-free) requests to be valid addresses
+    constexpr int C = (EPI == COL_SILU) ? 2 : (MT == 4 ? 4 : 8);
+    const int kchunk = (g.KT + WAVES - 1) / WAVES;
+    const bool all_waves_busy = g.KT >= WAVES && (WAVES - 1) * kchunk < g.KT;
+    const int n_sc = (kchunk + C - 1) / C;
+    if (!all_waves_busy) launch_one<EPI, MT, 0>(ctx, g, grid, e0, e1);
+    else if (n_sc >= 2) launch_one<EPI, MT, 2>(ctx, g, grid, e0, e1);
+    else launch_one<EPI, MT, 1>(ctx, g, grid, e0, e1);
 }
 
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     const bool wide = g.M > 32;
     switch (g.epi) {
-        case COL_STORE: wide ? launch_one<COL_STORE, 4>(ctx, g, grid, e0, e1) : launch_one<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
-        case COL_RESID: wide ? launch_one<COL_RESID, 4>(ctx, g, grid, e0, e1) : launch_one<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
-        case COL_SILU: wide ? launch_one<COL_SILU, 4>(ctx, g, grid, e0, e1) : launch_one<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
+        case COL_STORE: wide ? launch_npre<COL_STORE, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
+        case COL_RESID: wide ? launch_npre<COL_RESID, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
+        case COL_SILU: wide ? launch_npre<COL_SILU, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
         default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
