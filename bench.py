@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--corpus", type=int, default=0, help="C4: one corpus of this many ragged texts for the whole job (strong scaling)")
+    ap.add_argument("--eos-live", action="store_true", help="decode with end-of-sequence live (as a real checkpoint does) instead of fixed lengths")
     ap.add_argument("--tune", default="", help="comma-separated rt_debug_tune codes (100/101 legacy/column decode, 200/201 eager/graph)")
     args = ap.parse_args()
 
@@ -108,7 +109,9 @@ def main():
 
     cfg = config.PRESETS[args.model]()
     log(f"rank {rank}/{world}: building {cfg.name} engine (synthetic weights) ...")
-    eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=local_rank, max_batch=args.batch)
+    eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=local_rank, max_batch=args.batch, synthetic=True)
+    if args.eos_live:
+        eng.ignore_eos = False
     if args.greedy:
         eng.params.do_sample = False
     for code in [c for c in args.tune.split(",") if c]:

@@ -108,7 +108,17 @@ class ModelConfig:
         return self.talker.hidden != self.predictor.hidden
 
     def to_json(self) -> str:
-        return json.dumps(asdict(self), indent=1)
+        """``config.json`` of a checkpoint written by this package (weights.save_checkpoint): every field, under one key."""
+        return json.dumps({"rho_tts_amd": asdict(self)}, indent=1)
+
+    @staticmethod
+    def from_dict(d: dict) -> "ModelConfig":
+        d = dict(d)
+        talker, predictor, codec = TransformerDims(**d.pop("talker")), TransformerDims(**d.pop("predictor")), dict(d.pop("codec"))
+        for k in ("upsampling_ratios", "upsample_rates"):
+            codec[k] = tuple(codec[k])
+        d["role_ids"] = tuple(d["role_ids"])
+        return ModelConfig(talker=talker, predictor=predictor, codec=CodecDims(**codec), **d)
 
 
 def qwen3_tts_1p7b() -> ModelConfig:
@@ -171,7 +181,11 @@ def resolve(model_path: str) -> ModelConfig:
     (``Qwen/Qwen3-TTS-12Hz-1.7B-Base``, providers/qwen.py:57; UI catalogue ui/config.py:33-60)."""
     cfg_file = os.path.join(model_path, "config.json") if os.path.isdir(model_path) else None
     if cfg_file and os.path.exists(cfg_file):
-        return from_hf_config(json.load(open(cfg_file)), name=os.path.basename(model_path.rstrip("/")))
+        with open(cfg_file) as f:
+            js = json.load(f)
+        if "rho_tts_amd" in js:
+            return ModelConfig.from_dict(js["rho_tts_amd"])
+        return from_hf_config(js, name=os.path.basename(model_path.rstrip("/")))
     low = model_path.lower()
     for key in ("tiny", "small"):
         if low.endswith(key):
@@ -208,4 +222,18 @@ def from_hf_config(js: dict, name: str = "hf") -> ModelConfig:
             setattr(cfg, k, t[k])
     if "codec_eos_token_id" in t:
         cfg.codec_eos_id = t["codec_eos_token_id"]
+    if "max_position_embeddings" in t.get("text_config", t):       # the reference refines its segment limit from it (qwen.py:131-139)
+        cfg.max_positions = int(t.get("text_config", t)["max_position_embeddings"])
+    c2w = js.get("code2wav_config", js.get("speech_tokenizer_config", {}))
+    if c2w:
+        d = cfg.codec
+        for src, dst in (("codebook_size", "codebook_size"), ("num_quantizers", "num_quantizers"), ("hidden_size", "hidden"),
+                         ("num_hidden_layers", "layers"), ("num_attention_heads", "heads"), ("intermediate_size", "inter"),
+                         ("sliding_window", "sliding_window"), ("decoder_dim", "decoder_dim")):
+            if src in c2w:
+                setattr(d, dst, c2w[src])
+        if "upsample_rates" in c2w:
+            d.upsample_rates = tuple(c2w["upsample_rates"])
+        if "upsampling_ratios" in c2w:
+            d.upsampling_ratios = tuple(c2w["upsampling_ratios"])
     return cfg

@@ -227,6 +227,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 1400) { g_eos_check_every = std::max(1, skinny_variant - 1400); return RT_OK; }   // 14nn: look at the end-of-sequence flags every nn frames
     if (skinny_variant >= 1300) { g_sync_parts = skinny_variant - 1300; return RT_OK; }             // 1300/1301: stream sync after every frame part off/on
     if (skinny_variant >= 1200) { g_conv_win = skinny_variant - 1200; return RT_OK; }               // 1200/1201: conv input window in LDS off/on
     if (skinny_variant >= 1100) { g_final_conv = skinny_variant - 1100; return RT_OK; }             // 1100/1101: last conv as GEMM / own kernel

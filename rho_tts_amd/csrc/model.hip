@@ -1168,47 +1168,77 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     std::vector<int> produced(B, 0);
     int frames_run = 0;
     bool cancelled = false;
+    // End-of-sequence is decided on the device (the sampler writes one flag per item and frame); the host only needs the
+    // flags to know when to STOP launching, so it fetches them every `g_eos_check_every` frames instead of stalling the
+    // launch queue with a copy + wait per frame.  Frames launched past an item's end are wasted work on finished rows (the
+    // results are cut at the flag), at most g_eos_check_every - 1 of them at the very end of the batch.
+    const int eos_every = A->ignore_eos ? 0 : std::max(1, g_eos_check_every);
+    std::vector<int> lane_frames(n_lanes, 0);              // frame budget of a lane = its longest item
+    for (int l = 0; l < n_lanes; ++l)
+        for (int bb = lanes[l].b0; bb < lanes[l].b0 + lanes[l].n; ++bb) lane_frames[l] = std::max(lane_frames[l], A->h_max_frames[bb]);
+    int checked = 0;                                       // frames whose flags have been applied to done / produced
+    auto apply_frames = [&](int upto) {                    // bookkeeping of frames [checked, upto), in order
+        for (int t = checked; t < upto; ++t)
+            for (int bb = 0; bb < B; ++bb) {
+                if (done[bb]) continue;
+                if (eos_host[(size_t)t * B + bb]) done[bb] = 1;
+                else if (++produced[bb] >= A->h_max_frames[bb]) done[bb] = 1;
+            }
+        checked = upto;
+        bool all = true;
+        for (Lane& ln : lanes) {
+            bool lane_done = true;
+            for (int bb = ln.b0; bb < ln.b0 + ln.n; ++bb) lane_done = lane_done && done[bb];
+            ln.done = lane_done;
+            all = all && lane_done;
+        }
+        return all;
+    };
     for (int t = 0; t < T_max; ++t) {
         if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
         for (int l = 0; l < n_lanes; ++l) {
             Lane& ln = lanes[l];
-            if (ln.done) continue;
+            if (ln.done || t >= lane_frames[l]) continue;
             ctx->stream = ln.stream;
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l], ln.stream));
             else RT_TRY(enqueue_a(ln));
             if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
-            if (!A->ignore_eos)
-                RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)t * B + ln.b0, d_eos + (size_t)t * B + ln.b0, ln.n * 4, hipMemcpyDeviceToHost, ln.stream));
         }
         ctx->stream = main_stream;
         frames_run = t + 1;
-        // ---- stop bookkeeping (needs the eos flags on the host only when eos is live)
-        if (!A->ignore_eos)
-            for (Lane& ln : lanes) if (!ln.done) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
-        bool all_done = true;
-        for (Lane& ln : lanes) {
-            if (ln.done) continue;
-            bool lane_done = true;
-            for (int b = ln.b0; b < ln.b0 + ln.n; ++b) {
-                if (!done[b]) {
-                    if (eos_host[(size_t)t * B + b]) done[b] = 1;
-                    else if (++produced[b] >= A->h_max_frames[b]) done[b] = 1;
-                }
-                lane_done = lane_done && done[b];
+        bool all_done;
+        if (eos_every == 0) {
+            all_done = apply_frames(t + 1);                // no flags to wait for: the frame budgets alone decide
+        } else if ((t + 1) % eos_every == 0 || t + 1 == T_max) {
+            for (Lane& ln : lanes) {
+                if (ln.done) continue;
+                RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)checked * B, d_eos + (size_t)checked * B, (size_t)(t + 1 - checked) * B * 4,
+                                           hipMemcpyDeviceToHost, ln.stream));
+                RT_HIP(ctx, hipStreamSynchronize(ln.stream));
+                if (n_lanes == 1) break;
             }
-            ln.done = lane_done;
-            all_done = all_done && lane_done;
+            if (n_lanes > 1) for (Lane& ln : lanes) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
+            all_done = apply_frames(t + 1);
+        } else {
+            all_done = false;
         }
-        if (all_done) break;
+        if (all_done || t + 1 == T_max) break;
         for (int l = 0; l < n_lanes; ++l) {
             Lane& ln = lanes[l];
-            if (ln.done) continue;
+            if (ln.done || t + 1 >= lane_frames[l]) continue;
             ctx->stream = ln.stream;
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l + 1], ln.stream));
             else RT_TRY(enqueue_b(ln));
             if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         }
         ctx->stream = main_stream;
+    }
+    if (!cancelled && checked < frames_run) {              // (cancelled runs report nothing)
+        if (eos_every) {
+            for (Lane& ln : lanes) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
+            RT_HIP(ctx, hipMemcpy(eos_host.data() + (size_t)checked * B, d_eos + (size_t)checked * B, (size_t)(frames_run - checked) * B * 4, hipMemcpyDeviceToHost));
+        }
+        (void)apply_frames(frames_run);
     }
     // ---- join
     if (n_lanes > 1)

@@ -47,9 +47,31 @@ class GenerationParams:
         return RtSampling(int(ds), self.predictor_temperature, self.predictor_top_k, self.predictor_top_p, 1.0)
 
 
+SYNTHETIC_ENV = "RHO_TTS_AMD_SYNTHETIC"
+
+
+def find_checkpoint(model_path: str) -> bool:
+    return os.path.isdir(model_path) and any(f.endswith(".safetensors") for f in os.listdir(model_path))
+
+
 class Engine:
+    """``model_path`` is a local directory with ``*.safetensors`` (+ optional ``config.json`` / ``tokenizer.json``), as the
+    reference's ``from_pretrained`` accepts (providers/qwen.py:160-165).  There is no network here, so a hub id cannot be
+    resolved: without a local checkpoint the engine REFUSES to start unless seeded synthetic weights were asked for
+    explicitly (``synthetic=True`` or ``RHO_TTS_AMD_SYNTHETIC=1`` - benchmarks and parity tests) - it never hands random-weight
+    noise to a caller who asked for a real model."""
+
     def __init__(self, model_path: str = "Qwen/Qwen3-TTS-12Hz-1.7B-Base", device_ordinal: int = 0, max_batch: int = 32,
-                 weight_seed: int = 789, cfg: Optional[ModelConfig] = None, max_positions: Optional[int] = None):
+                 weight_seed: int = 789, cfg: Optional[ModelConfig] = None, max_positions: Optional[int] = None,
+                 synthetic: Optional[bool] = None):
+        has_ckpt = find_checkpoint(model_path)
+        if synthetic is None:
+            synthetic = (not has_ckpt) and os.environ.get(SYNTHETIC_ENV, "") not in ("", "0")
+        if not has_ckpt and not synthetic:
+            raise ValueError(                                  # a configuration error: never retried by the pipeline (base_tts.py:786-787)
+                f"no local checkpoint at {model_path!r}: expected a directory holding *.safetensors (this build cannot download "
+                f"{model_path!r}).  For seeded synthetic weights of that architecture (benchmarks, parity tests) pass "
+                f"synthetic=True or set {SYNTHETIC_ENV}=1.")
         self.cfg = cfg or resolve(model_path)
         self.model_path = model_path
         self.device_ordinal = device_ordinal
@@ -57,8 +79,9 @@ class Engine:
         self.ctx = _native.Context(device_ordinal)          # raises NativeUnavailable without a gfx950 GPU
         self.max_batch = max_batch
         self.model = NativeModel(self.ctx, self.cfg, max_batch=max_batch, max_positions=max_positions)
-        has_ckpt = os.path.isdir(model_path) and any(f.endswith(".safetensors") for f in os.listdir(model_path))
+        has_ckpt = has_ckpt and not synthetic
         self.synthetic = not has_ckpt
+        self.ignore_eos: Optional[bool] = None              # None: synthetic weights never emit EOS -> fixed lengths; real weights stop at EOS
         with torch.cuda.device(self.device):
             if has_ckpt:
                 state = load_safetensors(self.cfg, model_path, device=self.device)
@@ -113,8 +136,9 @@ class Engine:
         for i, f in zip(ids, frames):
             if len(i) + 2 + f > limit:
                 raise RuntimeError(f"length: text of {len(i)} tokens + {f} frames exceeds the {limit} free KV rows")
+        ignore_eos = self.synthetic if self.ignore_eos is None else bool(self.ignore_eos)
         return self.model.generate(ids, frames, self.params.talker(), self.params.predictor(), seed=seed, item_ids=item_ids,
-                                   ignore_eos=self.synthetic, cancel_flag=cancel_flag)
+                                   ignore_eos=ignore_eos, cancel_flag=cancel_flag)
 
     def vocode(self, codes: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Codec decoder with the reference architecture's chunking (chunk_frames + left_context_frames)."""

@@ -182,27 +182,99 @@ def synthetic_state(cfg: ModelConfig, seed: int = 789, device="cpu", only_prefix
     return out
 
 
+# Checkpoint tensor names -> this module's names.  The first group is the layout of the sibling architecture in the
+# container's transformers (Qwen3-Omni talker / code predictor / code2wav: modeling_qwen3_omni_moe.py); whether a real
+# Qwen3-TTS checkpoint uses exactly these is UNVERIFIED offline (no checkpoint, no qwen-tts source) - a name that matches
+# no rule is reported, never guessed.
+_HF_RULES = [
+    (r"^talker\.model\.codec_embedding\.", "talker.codec_embedding."),
+    (r"^talker\.model\.text_embedding\.", "talker.text_embedding."),
+    (r"^talker\.model\.(layers\.\d+\.|norm\.)", r"talker.\1"),
+    (r"^talker\.text_projection\.linear_fc1\.", "talker.text_projection.fc1."),
+    (r"^talker\.text_projection\.linear_fc2\.", "talker.text_projection.fc2."),
+    (r"^talker\.code_predictor\.model\.codec_embedding\.", "predictor.codec_embedding."),
+    (r"^talker\.code_predictor\.model\.(layers\.\d+\.|norm\.)", r"predictor.\1"),
+    (r"^talker\.code_predictor\.lm_head\.", "predictor.lm_head."),
+    (r"^talker\.code_predictor\.(small_to_mtp_projection|mtp_proj)\.", "predictor.mtp_proj."),
+    (r"^(code2wav|speech_tokenizer\.decoder)\.", "codec."),
+]
+
+
+def remap_name(name: str) -> str:
+    """A checkpoint's tensor name in this module's naming (identity when it already is)."""
+    import re
+    for pat, rep in _HF_RULES:
+        new, n = re.subn(pat, rep, name)
+        if n:
+            return new
+    return name
+
+
+def checkpoint_files(model_dir: str) -> List[str]:
+    """``*.safetensors`` in ``model_dir`` and one level of sub-folders (a speech-tokenizer folder next to the talker's shards)."""
+    out = []
+    for root, dirs, files in os.walk(model_dir):
+        if root != model_dir and os.path.dirname(root) != model_dir.rstrip("/"):
+            continue
+        out += [os.path.join(root, f) for f in sorted(files) if f.endswith(".safetensors")]
+    return sorted(out)
+
+
 def load_safetensors(cfg: ModelConfig, model_dir: str, device="cpu") -> Dict[str, torch.Tensor]:
-    """Load a checkpoint that uses this module's tensor names (bf16).  Nothing is executed from the files."""
+    """Load a checkpoint (this module's tensor names, or names `remap_name` knows) as bf16.  safetensors only:
+    nothing is executed from the files."""
     from safetensors import safe_open
 
     want = {sp[0]: sp[1] for sp in tensor_specs(cfg)}
     state: Dict[str, torch.Tensor] = {}
-    files = sorted(f for f in os.listdir(model_dir) if f.endswith(".safetensors"))
+    files = checkpoint_files(model_dir)
     if not files:
         raise FileNotFoundError(f"no .safetensors files in {model_dir}")
-    for f in files:
-        with safe_open(os.path.join(model_dir, f), framework="pt", device=str(device)) as sf:
+    unknown: List[str] = []
+    for path in files:
+        sub = os.path.relpath(os.path.dirname(path), model_dir)
+        with safe_open(path, framework="pt", device=str(device)) as sf:
             for k in sf.keys():
-                if k in want:
+                name = remap_name(k if sub == "." else f"{sub}.{k}")
+                if name not in want:
+                    name = remap_name(k)
+                if name in want:
                     tns = sf.get_tensor(k)
-                    if tuple(tns.shape) != tuple(want[k]):
-                        raise ValueError(f"{k}: checkpoint shape {tuple(tns.shape)} != configured {want[k]}")
-                    state[k] = tns.to(torch.bfloat16)
+                    if tuple(tns.shape) != tuple(want[name]):
+                        raise ValueError(f"{k}: checkpoint shape {tuple(tns.shape)} != configured {want[name]}")
+                    state[name] = tns.to(torch.bfloat16)
+                else:
+                    unknown.append(k)
     missing = sorted(set(want) - set(state))
     if missing:
-        raise ValueError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:4]}")
+        raise ValueError(f"checkpoint is missing {len(missing)} of {len(want)} tensors, e.g. {missing[:4]}"
+                         + (f"; {len(unknown)} tensors in the files matched no known name, e.g. {sorted(unknown)[:4]}" if unknown else ""))
     return state
+
+
+def save_checkpoint(cfg: ModelConfig, state: Dict[str, torch.Tensor], model_dir: str, shard_bytes: int = 1 << 30) -> List[str]:
+    """Write ``state`` as ``model-0000k.safetensors`` shards plus this package's ``config.json`` (what ``resolve`` reads back)."""
+    from safetensors.torch import save_file
+
+    os.makedirs(model_dir, exist_ok=True)
+    shards, cur, size = [], {}, 0
+    for k in sorted(state):
+        t = state[k].detach().to("cpu").contiguous()
+        if cur and size + t.numel() * t.element_size() > shard_bytes:
+            shards.append(cur)
+            cur, size = {}, 0
+        cur[k] = t
+        size += t.numel() * t.element_size()
+    if cur:
+        shards.append(cur)
+    paths = []
+    for i, sh in enumerate(shards):
+        path = os.path.join(model_dir, f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors")
+        save_file(sh, path)
+        paths.append(path)
+    with open(os.path.join(model_dir, "config.json"), "w") as f:
+        f.write(cfg.to_json())
+    return paths
 
 
 def param_count(cfg: ModelConfig) -> int:

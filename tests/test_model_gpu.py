@@ -320,7 +320,7 @@ def test_engine_chunked_vocode_matches_oracle_chunked_decode(ctx):
     architecture's chunked_decode): same waveform as the oracle's chunked_code2wav, RMSE < 1e-3; short and long items mixed."""
     from rho_tts_amd.engine import Engine
     cfg = config.PRESETS["tiny"]()
-    eng = Engine(cfg=cfg, model_path="tiny", device_ordinal=0, max_batch=4, weight_seed=789)
+    eng = Engine(cfg=cfg, model_path="tiny", device_ordinal=0, max_batch=4, weight_seed=789, synthetic=True)
     try:
         om = OracleModel(cfg, weights.synthetic_state(cfg, 789))
         g = torch.Generator().manual_seed(13)

@@ -161,3 +161,77 @@ def test_stream_cancel_and_config_errors(tiny_provider):
     r = c.generate("Built in voice")
     assert r is not None and r.audio.numel() > 0
     c.close()
+
+
+def test_checkpoint_directory_gives_the_same_audio_as_the_synthetic_state(tmp_path):
+    """a3: the loader path a real checkpoint takes (safetensors shards + config.json in a local directory, qwen.py:96-197) yields
+    the same model as the in-memory synthetic state it was written from: identical codes and waveforms at fixed lengths; and
+    with end-of-sequence live (what a real checkpoint decodes with) generation stays within its frame budget."""
+    from rho_tts_amd import weights
+    from rho_tts_amd.engine import Engine
+    cfg = config.tiny()
+    d = str(tmp_path / "tiny-CustomVoice")
+    weights.save_checkpoint(cfg, weights.synthetic_state(cfg, 789), d, shard_bytes=300_000)
+    texts = ["Hello there general test.", "One sentence only", "A third and rather longer sentence follows here."]
+    frames = [7, 5, 9]
+    a = Engine(d, device_ordinal=0, max_batch=4)
+    try:
+        assert not a.synthetic and a.cfg == cfg
+        a.ignore_eos = True
+        a.set_builtin_voice("ryan")
+        wa = [w.cpu() for w in a.synthesize(texts, seed=5, max_frames=frames)]
+        a.ignore_eos = None                                  # as a checkpoint decodes: stop at EOS, budget 8 + 6 frames per token
+        live = a.generate_codes(texts, seed=5)
+        for t, c in zip(texts, live):
+            assert 0 <= c.shape[0] <= a.frames_for(t, len(a.tokenizer.encode(t)))
+    finally:
+        a.close()
+    b = Engine("tiny", device_ordinal=0, max_batch=4, synthetic=True)
+    try:
+        b.set_builtin_voice("ryan")
+        wb = [w.cpu() for w in b.synthesize(texts, seed=5, max_frames=frames)]
+    finally:
+        b.close()
+    assert all(torch.equal(x, y) for x, y in zip(wa, wb))
+    # ... and through the provider (model path containing "CustomVoice" -> built-in speaker, qwen.py:231)
+    tts = MI355XQwenTTS(model_path=d, speaker="Ryan", batch_size=4)
+    try:
+        res = tts.generate(texts[:2])
+        assert res is not None and all(r is not None and r.audio.numel() > 0 for r in res)
+    finally:
+        tts.close()
+
+
+def test_eos_checked_every_k_frames_equals_every_frame():
+    """End-of-sequence flags live on the device; the host looks at them every 8 frames (rt_debug_tune 1408) instead of copying
+    and waiting every frame (1401).  Same codes and lengths either way, with forced and with sampled EOS."""
+    from rho_tts_amd import _native, weights
+    from rho_tts_amd._native_model import NativeModel, RtSampling
+    cfg = config.tiny()
+    ctx = _native.Context(0)
+    nm = NativeModel(ctx, cfg, max_batch=8)
+    try:
+        nm.load_state({k: v.cuda() for k, v in weights.synthetic_state(cfg, 789).items()})
+        nm.set_voice("chinese", "ryan", None, [], None)
+        G = cfg.n_groups
+        g = torch.Generator().manual_seed(3)
+        texts = [[int(v) for v in torch.randint(0, 400, (int(n),), generator=g)] for n in (3, 5, 2, 7, 4)]
+        frames = [30, 21, 12, 26, 30]
+        eos = cfg.codec_eos_id
+        forced = [torch.randint(0, 60, (f, G), generator=g) for f in frames]
+        forced[0][17, 0] = eos                          # ends at frame 17 (not a multiple of 8)
+        forced[1][8, 0] = eos                           # ends exactly at a check boundary
+        forced[3][3, 0] = eos
+        out = {}
+        for every in (1, 8, 5):
+            nm.lib.rt_debug_tune(1400 + every, 0)
+            out[every] = (nm.generate(texts, frames, RtSampling(0, 1, 1, 1, 1), ignore_eos=False, forced_codes=forced),
+                          nm.generate(texts, frames, RtSampling(1, 1.5, 64, 1.0, 1.0), seed=11, ignore_eos=False, min_frames=2))
+        assert [c.shape[0] for c in out[1][0]] == [17, 8, 12, 3, 30]
+        for every in (8, 5):
+            for a, b in zip(out[1], out[every]):
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+    finally:
+        nm.lib.rt_debug_tune(1408, 0)
+        nm.close()
+        ctx.close()

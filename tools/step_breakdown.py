@@ -9,7 +9,7 @@ from rho_tts_amd.engine import Engine
 from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
 
 cfg = config.PRESETS["1.7b"]()
-eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32)
+eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32, synthetic=True)
 for code in sys.argv[1:]:
     eng.ctx.lib.rt_debug_tune(int(code), 0)
 texts = bench.sentences(32, 10, seed=789)
