@@ -228,6 +228,21 @@ def main():
         extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(c_frames)), "padding_efficiency": round(pad_eff, 4),
                       "batches_per_rank": [len(pl) for pl in plans]})
 
+    # time to first audio of the streaming entry (BaseTTS.stream yields per segment, base_tts.py:1132-1190): one text alone,
+    # call -> decoded, vocoded, post-processed, 16-bit PCM of the first segment on the host
+    if rank == 0 and not args.no_roofline:
+        one = sentences(1, args.words, seed=4242)
+        tt = []
+        for _ in range(3):
+            sync()
+            t1 = time.perf_counter()
+            raw1 = eng.synthesize(one, seed=789, item_ids=[0])
+            o1, _s = eng.post_process([[raw1[0]]], post)
+            _pcm = eng.ctx.pcm16(o1[0]).cpu()
+            tt.append((time.perf_counter() - t1) * 1e3)
+        extra["ttfa_ms_one_text"] = round(min(tt), 2)
+        extra["ttfa_audio_s"] = round(o1[0].numel() / cfg.sample_rate, 2)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, args, eng)

@@ -343,7 +343,7 @@ class BaseTTS(ABC):
                     try:
                         target = output_path if single else f"{output_path}_{idx}.wav"
                         wav_path = target if format == "wav" else (target.rsplit(".", 1)[0] + ".wav" if "." in target else target + ".wav")
-                        mono = audio.detach().cpu()
+                        mono = audio.detach()                # (a provider may convert to PCM on the device before the copy)
                         self._save_wav(wav_path, mono.unsqueeze(0) if mono.dim() == 1 else mono, self.sample_rate)
                         res.path = wav_path if format == "wav" else self._convert_format(wav_path, format)
                     except FormatConversionError:

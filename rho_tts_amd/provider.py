@@ -105,9 +105,9 @@ class BatchedPipeline:
     # one entry of `work` per (item, segment index, text); returns the accepted audio (or None) per entry
     def _generate_work(self, work, plans, token, progress_callback, scores):
         accepted: List[Optional[torch.Tensor]] = [None] * len(work)
-        best: List[Optional[torch.Tensor]] = [None] * len(work)
-        best_drift = [float("inf")] * len(work)
-        last: List[Optional[torch.Tensor]] = [None] * len(work)
+        # per-segment validation state, exactly the reference's locals (base_tts.py:765-768): best audio by drift, the
+        # MINIMUM drift seen, the LAST text similarity computed (whenever the voice check passed), the last audio
+        state = [{"best": None, "best_drift": float("inf"), "text_sim": None, "last": None} for _ in work]
         todo = list(range(len(work)))
         bs = max(1, int(getattr(self, "batch_size", 1)))
         for iteration in range(self.max_iterations):
@@ -130,30 +130,28 @@ class BatchedPipeline:
                     if a is None:
                         retry.append(w)
                         continue
-                    last[w] = a
+                    state[w]["last"] = a
                     if self.max_iterations == 1:
+                        state[w]["best"] = a
                         accepted[w] = a
                         continue
-                    verdict = self._validate_segment(a, work[w][2])
-                    if verdict is None:                      # validation raised: counts as a failed attempt
-                        retry.append(w)
-                        continue
-                    drift, voice_ok, sim, text_ok = verdict
-                    if drift < best_drift[w]:
-                        best_drift[w], best[w] = drift, a
-                    i = work[w][0]
-                    if voice_ok and text_ok:
-                        accepted[w] = a
-                        scores[i][0].append(drift)
-                        if sim is not None:
-                            scores[i][1].append(sim)
+                    if self._validate_segment(a, work[w][2], state[w]):
+                        accepted[w] = a                      # valid: this attempt's audio is kept (:859)
                     else:
                         retry.append(w)
             todo = retry
-        for w in todo:                                       # iterations exhausted: best by drift, else the last audio
-            accepted[w] = best[w] if best[w] is not None else last[w]
-            if best[w] is not None and best_drift[w] != float("inf"):
-                scores[work[w][0]][0].append(best_drift[w])
+        for w in todo:                                       # iterations exhausted: best by drift, else the last audio (:887-898)
+            st = state[w]
+            accepted[w] = st["best"] if st["best"] is not None else st["last"]
+        if self.max_iterations > 1:
+            for w, a in enumerate(accepted):                 # scores of every segment that produced audio (:901-906)
+                if a is None:
+                    continue
+                i = work[w][0]
+                if state[w]["best_drift"] != float("inf"):
+                    scores[i][0].append(state[w]["best_drift"])
+                if state[w]["text_sim"] is not None:
+                    scores[i][1].append(state[w]["text_sim"])
         return accepted
 
     def _estimate_cost(self, segment: str) -> Optional[float]:
@@ -206,33 +204,53 @@ class BatchedPipeline:
         logger.warning(f"    generation error ({e})")
         return None
 
-    def _validate_segment(self, audio: torch.Tensor, text: str):
-        """Temp-WAV round trip through the reference's validators (base_tts.py:821-886); only reachable when
-        ``max_iterations > 1`` and the host package provides them."""
-        import os
-        import tempfile
+    def _validate_segment(self, audio: torch.Tensor, text: str, st: dict) -> bool:
+        """One validation attempt (base_tts.py:821-886), updating the segment's state in the reference's order: drift ->
+        auto-sort -> best-by-drift -> text match only if the voice passed.  A validator that raises counts as a failed
+        attempt but keeps what it had already recorded.  Returns True when the attempt is accepted."""
         if not hasattr(self, "_validate_accent_drift"):
-            return (0.0, True, None, True)
-        fd, path = tempfile.mkstemp(suffix=".wav", prefix="rho_tts_validate_")
-        os.close(fd)
+            st["best"] = audio
+            return True
         try:
-            mono = audio.detach().cpu()
-            self._save_wav(path, mono.unsqueeze(0) if mono.dim() == 1 else mono, self.sample_rate)
-            drift, voice_ok = self._validate_accent_drift(path)
-            if hasattr(self, "_auto_sort_audio"):
-                self._auto_sort_audio(path, drift)
-            sim, text_ok = None, True
-            if voice_ok:
-                text_ok, sim, _ = self._validate_text_match(path, text)
-            return (drift, voice_ok, sim, text_ok)
+            with self._validation_input(audio) as path:
+                drift, voice_ok = self._validate_accent_drift(path)
+                if hasattr(self, "_auto_sort_audio"):
+                    self._auto_sort_audio(path, drift)
+                if drift < st["best_drift"]:
+                    st["best_drift"], st["best"] = drift, audio.clone()
+                text_ok = True
+                if voice_ok:
+                    text_ok, sim, _ = self._validate_text_match(path, text)
+                    st["text_sim"] = sim
+                if voice_ok and text_ok:
+                    st["best"] = audio
+                    return True
+                return False
         except Exception as e:  # noqa: BLE001
             logger.warning(f"    validation error ({e})")
-            return None
-        finally:
+            return False
+
+    def _validation_input(self, audio: torch.Tensor):
+        """What the validators are handed: the reference's file-based validators get a temporary 16-bit WAV
+        (base_tts.py:821-830), written from a device-side int16 conversion when the audio lives on the GPU."""
+        import contextlib
+        import os
+        import tempfile
+
+        @contextlib.contextmanager
+        def cm():
+            fd, path = tempfile.mkstemp(suffix=".wav", prefix="rho_tts_validate_")
+            os.close(fd)
             try:
-                os.remove(path)
-            except OSError:
-                pass
+                mono = audio.detach()
+                self._save_wav(path, mono.unsqueeze(0) if mono.dim() == 1 else mono, self.sample_rate)
+                yield path
+            finally:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+        return cm()
 
 
 class HipAudioLeaves:
@@ -288,6 +306,20 @@ class HipAudioLeaves:
             return 1.0, True
         _, (s,) = self._post([[audio]], _native.POST_DECAY)
         return s.decay_ratio, bool(s.decay_ok)
+
+    def _save_wav(self, path: str, audio: torch.Tensor, sample_rate: int) -> None:
+        """Output stage (base_tts.py:654-671).  A waveform that still lives in HBM is converted to the reference's 16-bit PCM
+        (clip, x 32767, truncate - the stdlib fallback's definition) ON the device and crosses PCIe as int16: half the bytes of
+        the float32 copy the reference makes first (:807,824,1046).  CPU tensors take the host API's own writer."""
+        if not audio.is_cuda:
+            return super()._save_wav(path, audio, sample_rate)
+        import wave
+        pcm = self._native_ctx().pcm16(audio).cpu().numpy()
+        with wave.open(path, "wb") as wf:
+            wf.setnchannels(1)
+            wf.setsampwidth(2)
+            wf.setframerate(sample_rate)
+            wf.writeframes(pcm.tobytes())
 
     def _finish_items(self, items: Sequence[Sequence[torch.Tensor]]):
         """join -> loudness -> decay for every item, one launch (base_tts.py:912-926)."""

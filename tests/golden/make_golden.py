@@ -68,6 +68,43 @@ def fake_wave(text: str) -> np.ndarray:
     return w.astype(np.float32)
 
 
+# Scripted validators shared with tests/test_pipeline_host.py (kept identical there): the drift of an attempt is looked up by
+# the length of the WAV it is handed (fake_wave gives every text its own length) and the attempt number, the text similarity
+# by text and attempt number.
+VALIDATION_TEXTS = ["Accepted on the third try", "Fine at once", "Never good enough at all"]
+DRIFT_SCRIPT = {VALIDATION_TEXTS[0]: [0.5, 0.1, 0.3], VALIDATION_TEXTS[1]: [0.05], VALIDATION_TEXTS[2]: [0.4, 0.6, 0.2]}
+SIM_SCRIPT = {VALIDATION_TEXTS[0]: [0.5, 0.9], VALIDATION_TEXTS[1]: [0.95], VALIDATION_TEXTS[2]: []}
+
+
+def install_scripted_validators(t, drift_threshold=0.35, sim_threshold=0.85):
+    import wave
+    by_len = {int(fake_wave(x).shape[0]): x for x in VALIDATION_TEXTS}
+    assert len(by_len) == len(VALIDATION_TEXTS)
+    t.drift_calls, t.text_calls = [], []
+    n_drift, n_text = {}, {}
+
+    def drift(path):
+        with wave.open(path, "rb") as wf:
+            text = by_len[wf.getnframes()]
+        k = n_drift.get(text, 0)
+        n_drift[text] = k + 1
+        d = DRIFT_SCRIPT[text][k]
+        t.drift_calls.append([text, d])
+        return d, d < drift_threshold
+
+    def text_match(path, text):
+        k = n_text.get(text, 0)
+        n_text[text] = k + 1
+        s = SIM_SCRIPT[text][k]
+        t.text_calls.append([text, s])
+        return s >= sim_threshold, s, "transcribed " + text
+
+    t._validate_accent_drift = drift
+    t._validate_text_match = text_match
+    t._auto_sort_audio = lambda path, drift_prob: None
+    t._log_text_diff = lambda a, b: None
+
+
 def tone(n, f, amp=0.3, dc=0.0):
     i = np.arange(n, dtype=np.float64)
     return (amp * np.sin(2 * np.pi * f * i / SR) + dc).astype(np.float32)
@@ -191,6 +228,9 @@ def main():
                             "abs_sum": float(np.abs(a.astype(np.float64)).sum()),
                             "decay_ratio": float(meta["decay_ratio"]),
                             "meta_keys": sorted(meta.keys())})
+                for k in ("drift_prob", "text_similarity"):
+                    if k in meta:
+                        rec[-1][k] = float(meta[k])
         return rec
 
     t = Fake()
@@ -220,6 +260,16 @@ def main():
     t.phonetic_mapping = {"exocrine": "exo-crene"}
     texts = ["The exocrine gland"]
     pipe["phonetic"] = {"texts": texts, "out": run(t, texts), "calls": list(t.calls)}
+
+    # validation with retries (max_iterations = 3) and scripted validators: which audio is kept and which scores are reported
+    # (minimum drift over the attempts, last text similarity; base_tts.py:821-906)
+    t = Fake()
+    t._max_chars_explicit = True
+    t.max_iterations = 3
+    install_scripted_validators(t)
+    texts = list(VALIDATION_TEXTS)
+    pipe["validated_retries"] = {"texts": texts, "out": run(t, texts), "calls": list(t.calls), "drift_calls": list(t.drift_calls),
+                                 "text_calls": list(t.text_calls)}
 
     seg_cases = {}
     t = Fake()

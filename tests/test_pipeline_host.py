@@ -1,4 +1,6 @@
-"""Host logic of the provider against the reference-generated pipeline fixtures
+"""(Runs against whichever host API rho_tts_amd.api resolved: the mirror normally, the reference's own package when it is
+importable - tests/test_dropin_reference.py runs this whole file in that mode.)
+Host logic of the provider against the reference-generated pipeline fixtures
 (tests/golden/pipeline_golden.json, produced by tests/golden/make_golden.py from the reference's own
 BaseTTS._run_pipeline with a deterministic fake provider).  The numeric leaves are supplied by the CPU
 oracle here (no GPU in this suite); tests/test_provider_gpu.py repeats the comparison with the HIP leaves."""
@@ -10,7 +12,7 @@ import pytest
 import torch
 
 from oracle import postprocess as OP
-from rho_tts_amd import hostapi
+from rho_tts_amd import api, hostapi
 from rho_tts_amd.provider import BatchedPipeline
 
 SR = 24000
@@ -35,7 +37,7 @@ class OracleLeaves:
         return [OP.finish_item(list(it), p, loudness=False) for it in items]
 
 
-class Fake(BatchedPipeline, OracleLeaves, hostapi.BaseTTS):
+class Fake(BatchedPipeline, OracleLeaves, api.BaseTTS):
     def __init__(self, batch_size=1, **kw):
         super().__init__(device="cpu", **kw)
         self.batch_size = batch_size
@@ -61,7 +63,7 @@ class Fake(BatchedPipeline, OracleLeaves, hostapi.BaseTTS):
 
 
 def run(tts, texts, token=None, cb=None):
-    res = tts._run_pipeline(texts, token or hostapi.CancellationToken(), cb)
+    res = tts._run_pipeline(texts, token or api.CancellationToken(), cb)
     rec = []
     for r in res:
         if r is None:
@@ -123,7 +125,7 @@ def test_value_error_propagates_and_other_runtime_errors_too():
     t = Fake(); t._max_chars_explicit = True
     t.value_error_on = {"b"}
     with pytest.raises(ValueError):
-        t._run_pipeline(["a", "b"], hostapi.CancellationToken())
+        t._run_pipeline(["a", "b"], api.CancellationToken())
     with pytest.raises(ValueError):
         t.generate(["a", "b"])                                        # generate() re-raises ValueError (base_tts.py:1096-1097)
 
@@ -131,18 +133,18 @@ def test_value_error_propagates_and_other_runtime_errors_too():
         def _generate_audio(self, text, **kw):
             raise RuntimeError("device lost")
     with pytest.raises(RuntimeError):
-        Boom()._run_pipeline(["a"], hostapi.CancellationToken())
+        Boom()._run_pipeline(["a"], api.CancellationToken())
     assert Boom().generate("a") is None                                # ... but generate() swallows it and returns None
 
 
 def test_cancellation_raises_inside_and_returns_none_outside():
     t = Fake(batch_size=2); t._max_chars_explicit = True
-    tok = hostapi.CancellationToken()
+    tok = api.CancellationToken()
     tok.cancel()
-    with pytest.raises(hostapi.CancelledException):
+    with pytest.raises(api.CancelledException):
         t._run_pipeline(["a", "b"], tok)
     assert t.generate(["a", "b"], cancellation_token=tok) is None
-    tok2 = hostapi.CancellationToken()
+    tok2 = api.CancellationToken()
     t2 = Fake(batch_size=1); t2._max_chars_explicit = True
     seen = []
 
@@ -150,7 +152,7 @@ def test_cancellation_raises_inside_and_returns_none_outside():
         seen.append(msg)
         if len(seen) == 2:
             tok2.cancel()
-    with pytest.raises(hostapi.CancelledException):
+    with pytest.raises(api.CancelledException):
         t2._run_pipeline(["One.", "Two.", "Three.", "Four."], tok2, cb)
     assert len(t2.calls) == 2                                          # cancelled between segments, nothing further generated
 
@@ -162,7 +164,7 @@ def test_decay_retry_regenerates_whole_item_then_gives_best():
             fix = lambda a: a * torch.linspace(1.0, 0.0, a.numel()) if self.seed == 789 else a
             return fix(out) if isinstance(text, str) else [fix(a) for a in out]
     t = Decaying(); t._max_chars_explicit = True
-    res = t._run_pipeline(["Hello world"], hostapi.CancellationToken())
+    res = t._run_pipeline(["Hello world"], api.CancellationToken())
     assert len(t.calls) == 2 and t.seed != 789                          # one regeneration with a wall-clock seed
     assert res[0][2]["decay_ratio"] >= 0.3
 
@@ -172,7 +174,7 @@ def test_decay_retry_regenerates_whole_item_then_gives_best():
             f = lambda a: a * torch.linspace(1.0, 0.0, a.numel())
             return f(out) if isinstance(text, str) else [f(a) for a in out]
     t = Always(); t._max_chars_explicit = True
-    res = t._run_pipeline(["Hello world"], hostapi.CancellationToken())
+    res = t._run_pipeline(["Hello world"], api.CancellationToken())
     assert len(t.calls) == t.max_decay_retries and res[0] is not None and res[0][2]["decay_ratio"] < 0.3
 
 
@@ -188,10 +190,10 @@ def test_validation_loop_only_runs_when_max_iterations_gt_1():
             calls["text"] += 1
             return True, 0.93, text
     t = V(); t._max_chars_explicit = True
-    t._run_pipeline(["Hello"], hostapi.CancellationToken())
+    t._run_pipeline(["Hello"], api.CancellationToken())
     assert calls == {"drift": 0, "text": 0}                              # max_iterations == 1: no validation at all
     t = V(); t._max_chars_explicit = True; t.max_iterations = 3
-    res = t._run_pipeline(["Hello"], hostapi.CancellationToken())
+    res = t._run_pipeline(["Hello"], api.CancellationToken())
     assert calls == {"drift": 2, "text": 1} and len(t.calls) == 2
     assert res[0][2]["drift_prob"] == 0.05 and res[0][2]["text_similarity"] == 0.93
     assert sorted(res[0][2]) == ["decay_ratio", "drift_prob", "text_similarity"]
@@ -200,7 +202,7 @@ def test_validation_loop_only_runs_when_max_iterations_gt_1():
 def test_generate_modes_and_files(tmp_path):
     t = Fake(batch_size=8); t._max_chars_explicit = True
     r = t.generate("Hello there")
-    assert isinstance(r, hostapi.GenerationResult) and r.path is None and r.sample_rate == SR and r.segments_count == 1
+    assert isinstance(r, api.GenerationResult) and r.path is None and r.sample_rate == SR and r.segments_count == 1
     assert abs(r.duration_sec - r.audio.numel() / SR) < 1e-9 and r.decay_ratio is not None and r.drift_prob is None
     rs = t.generate(["One", "Two"], output_path=str(tmp_path / "out"))
     assert [x.path for x in rs] == [str(tmp_path / "out_0.wav"), str(tmp_path / "out_1.wav")]
@@ -211,7 +213,7 @@ def test_generate_modes_and_files(tmp_path):
     assert np.array_equal(pcm, OP.pcm16(rs[0].audio))
     one = t.generate("Solo", output_path=str(tmp_path / "solo.wav"))
     assert one.path == str(tmp_path / "solo.wav")
-    with pytest.raises(hostapi.FormatConversionError):
+    with pytest.raises(api.FormatConversionError):
         t.generate("x", format="aiff")
     t.fail_on = {"bad"}
     assert t.generate("bad") is None and t.generate(["bad", "bad"]) is None
@@ -220,18 +222,18 @@ def test_generate_modes_and_files(tmp_path):
 
 
 def test_factory_registration_contract():
-    saved = dict(hostapi.TTSFactory._providers)
+    saved = dict(api.TTSFactory._providers)
     try:
-        hostapi.TTSFactory.register_provider("fake", Fake)
-        assert "fake" in hostapi.TTSFactory.list_providers()
-        assert isinstance(hostapi.TTSFactory.get_tts_instance("fake", batch_size=2), Fake)
+        api.TTSFactory.register_provider("fake", Fake)
+        assert "fake" in api.TTSFactory.list_providers()
+        assert isinstance(api.TTSFactory.get_tts_instance("fake", batch_size=2), Fake)
         with pytest.raises(TypeError):
-            hostapi.TTSFactory.register_provider("nope", dict)
-        with pytest.raises(hostapi.ProviderNotFoundError):
-            hostapi.TTSFactory.get_tts_instance("missing")
-        hostapi.TTSFactory.register_provider("fake", Fake)              # last write wins, silently
+            api.TTSFactory.register_provider("nope", dict)
+        with pytest.raises(api.ProviderNotFoundError):
+            api.TTSFactory.get_tts_instance("missing")
+        api.TTSFactory.register_provider("fake", Fake)              # last write wins, silently
     finally:
-        hostapi.TTSFactory._providers = saved
+        api.TTSFactory._providers = saved
 
 
 def test_async_and_token_threading():
@@ -239,13 +241,13 @@ def test_async_and_token_threading():
     t = Fake(); t._max_chars_explicit = True
     r = asyncio.run(t.async_generate("Hello"))
     assert r is not None and r.audio.numel() > 0
-    tok = hostapi.CancellationToken()
+    tok = api.CancellationToken()
     th = threading.Thread(target=tok.cancel)
     th.start(); th.join()
     assert tok.is_cancelled()
     tok.reset()
     assert not tok.is_cancelled()
-    with pytest.raises(hostapi.CancelledException):
+    with pytest.raises(api.CancelledException):
         tok.cancel(); tok.raise_if_cancelled()
 
 
@@ -265,3 +267,70 @@ def test_provider_constructor_contract_without_gpu():
         assert issubclass(MI355XQwenTTS, api.BaseTTS)
     finally:
         api.TTSFactory._providers = saved
+
+
+# ---- scripted validators: identical to tests/golden/make_golden.py (which cannot be imported here: it imports the reference)
+VALIDATION_TEXTS = ["Accepted on the third try", "Fine at once", "Never good enough at all"]
+DRIFT_SCRIPT = {VALIDATION_TEXTS[0]: [0.5, 0.1, 0.3], VALIDATION_TEXTS[1]: [0.05], VALIDATION_TEXTS[2]: [0.4, 0.6, 0.2]}
+SIM_SCRIPT = {VALIDATION_TEXTS[0]: [0.5, 0.9], VALIDATION_TEXTS[1]: [0.95], VALIDATION_TEXTS[2]: []}
+
+
+def install_scripted_validators(t, drift_threshold=0.35, sim_threshold=0.85):
+    import wave
+    by_len = {int(fake_wave(x).shape[0]): x for x in VALIDATION_TEXTS}
+    t.drift_calls, t.text_calls = [], []
+    n_drift, n_text = {}, {}
+
+    def drift(path):
+        with wave.open(path, "rb") as wf:
+            text = by_len[wf.getnframes()]
+        k = n_drift.get(text, 0)
+        n_drift[text] = k + 1
+        d = DRIFT_SCRIPT[text][k]
+        t.drift_calls.append([text, d])
+        return d, d < drift_threshold
+
+    def text_match(path, text):
+        k = n_text.get(text, 0)
+        n_text[text] = k + 1
+        s = SIM_SCRIPT[text][k]                 # (raises for the third text: a validator that fails counts as a failed attempt)
+        t.text_calls.append([text, s])
+        return s >= sim_threshold, s, "transcribed " + text
+
+    t._validate_accent_drift = drift
+    t._validate_text_match = text_match
+    t._auto_sort_audio = lambda path, drift_prob: None
+    t._log_text_diff = lambda a, b: None
+
+
+@pytest.mark.parametrize("bs", [1, 2, 32])
+def test_validation_retries_keep_the_references_scores(golden_pipe, bs):
+    """max_iterations = 3 with scripted validators: the audio kept and the reported drift_prob (MINIMUM over the attempts, even
+    when a later attempt is the accepted one) / text_similarity (LAST one computed) equal the reference's _run_pipeline
+    (base_tts.py:821-906), including a validator that raises after the drift was recorded."""
+    c = golden_pipe["validated_retries"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True
+    t.max_iterations = 3
+    install_scripted_validators(t)
+    got = run_with_scores(t, c["texts"])
+    same(got, c["out"])
+    for g, w in zip(got, c["out"]):
+        for k in ("drift_prob", "text_similarity"):
+            assert (k in g) == (k in w) and (k not in w or abs(g[k] - w[k]) < 1e-12), (k, g, w)
+    # every attempt the reference made was made (batching interleaves the texts, so compare per text)
+    for text in c["texts"]:
+        assert [d for tx, d in t.drift_calls if tx == text] == [d for tx, d in c["drift_calls"] if tx == text]
+        assert [s for tx, s in t.text_calls if tx == text] == [s for tx, s in c["text_calls"] if tx == text]
+        assert t.calls.count(text) == c["calls"].count(text)
+
+
+def run_with_scores(tts, texts):
+    res = tts._run_pipeline(texts, api.CancellationToken(), None)
+    rec = []
+    for a, nseg, meta in res:
+        a = a.reshape(-1).numpy()
+        r = {"len": int(a.shape[0]), "segments": int(nseg), "abs_sum": float(np.abs(a.astype(np.float64)).sum()),
+             "decay_ratio": float(meta["decay_ratio"]), "meta_keys": sorted(meta.keys())}
+        r.update({k: float(meta[k]) for k in ("drift_prob", "text_similarity") if k in meta})
+        rec.append(r)
+    return rec
