@@ -16,6 +16,7 @@ What differs from the reference, on purpose:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import logging
 import threading
@@ -204,23 +205,39 @@ class BatchedPipeline:
         logger.warning(f"    generation error ({e})")
         return None
 
+    # Optional tensor-level validators: callables on the waveform the provider still holds (GPU or CPU,
+    # 1-D float32) - when both are set a segment is validated without the reference's temp-WAV round trip
+    # (base_tts.py:821-830); either one alone replaces its file-based counterpart.
+    drift_scorer = None        # Callable[[torch.Tensor, int], float]            -> accent-drift probability
+    transcriber = None         # Callable[[torch.Tensor, int], Optional[str]]    -> transcription (None = failed)
+
     def _validate_segment(self, audio: torch.Tensor, text: str, st: dict) -> bool:
         """One validation attempt (base_tts.py:821-886), updating the segment's state in the reference's order: drift ->
         auto-sort -> best-by-drift -> text match only if the voice passed.  A validator that raises counts as a failed
         attempt but keeps what it had already recorded.  Returns True when the attempt is accepted."""
-        if not hasattr(self, "_validate_accent_drift"):
+        scorer, transcriber = getattr(self, "drift_scorer", None), getattr(self, "transcriber", None)
+        if scorer is None and not hasattr(self, "_validate_accent_drift"):
             st["best"] = audio
             return True
+        need_file = scorer is None or transcriber is None or bool(getattr(self, "auto_sort_good_dir", None) or getattr(self, "auto_sort_bad_dir", None))
         try:
-            with self._validation_input(audio) as path:
-                drift, voice_ok = self._validate_accent_drift(path)
-                if hasattr(self, "_auto_sort_audio"):
+            with (self._validation_input(audio) if need_file else contextlib.nullcontext(None)) as path:
+                if scorer is not None:
+                    drift = float(scorer(audio, self.sample_rate))
+                    voice_ok = drift < self.accent_drift_threshold
+                else:
+                    drift, voice_ok = self._validate_accent_drift(path)
+                if path is not None and hasattr(self, "_auto_sort_audio"):
                     self._auto_sort_audio(path, drift)
                 if drift < st["best_drift"]:
                     st["best_drift"], st["best"] = drift, audio.clone()
                 text_ok = True
                 if voice_ok:
-                    text_ok, sim, _ = self._validate_text_match(path, text)
+                    if transcriber is not None:
+                        from .validation import validate_text_match
+                        text_ok, sim, _ = validate_text_match(transcriber(audio, self.sample_rate), text, self.text_similarity_threshold)
+                    else:
+                        text_ok, sim, _ = self._validate_text_match(path, text)
                     st["text_sim"] = sim
                 if voice_ok and text_ok:
                     st["best"] = audio
@@ -233,7 +250,6 @@ class BatchedPipeline:
     def _validation_input(self, audio: torch.Tensor):
         """What the validators are handed: the reference's file-based validators get a temporary 16-bit WAV
         (base_tts.py:821-830), written from a device-side int16 conversion when the audio lives on the GPU."""
-        import contextlib
         import os
         import tempfile
 

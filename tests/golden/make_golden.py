@@ -105,6 +105,43 @@ def install_scripted_validators(t, drift_threshold=0.35, sim_threshold=0.85):
     t._log_text_diff = lambda a, b: None
 
 
+def text_similarity_fixtures():
+    """Pairs scored by the reference's calculate_text_similarity (validation/stt/stt_validator.py:188-232).  The module
+    imports its number normaliser at import time, which needs NeMo (absent): the normaliser module is stubbed with a function
+    that raises, which the reference catches per call (stt_validator.py:27-31) - and the pairs hold no numerals anyway."""
+    stub = types.ModuleType("rho_tts.validation.stt.number_normalizer")
+
+    def _absent(text):
+        raise RuntimeError("number normalisation unavailable offline")
+    stub.normalize_numbers_to_digits = _absent
+    sys.modules["rho_tts.validation.stt.number_normalizer"] = stub
+    import logging
+    logging.getLogger("rho_tts.validation.stt.stt_validator").setLevel(logging.ERROR)
+    from rho_tts.validation.stt import stt_validator as V
+    base = ["The quick brown fox jumps over the lazy dog.", "Hello there, General Kenobi!", "A well-known state-of-the-art method",
+            "It's a long established fact that a reader will be distracted", "Supercalifragilisticexpialidocious is extraordinarily long",
+            "to be or not to be", "An apple a day keeps the doctor away", "one", "I am", ""]
+    variants = ["the quick brown fox jumps over the lazy dog", "quick brown fox jumped over lazy dogs", "The quick brown fax jumps over the hazy dog",
+                "hello there general kenobi", "Hello their, general Kenobe", "a well known state of the art method", "well known state of art methods",
+                "its a long established fact that a reader will be distracted", "It is a long-established fact the reader would be distracted",
+                "supercalifragilisticexpialidocius is extraordinarly long", "super cali fragilistic is extra ordinarily long", "to be or not to bee",
+                "be to not or be to", "an apple the day keeps doctors away", "apples a day keep the doctor away from me and you and everyone",
+                "one", "won", "I am", "i'm", "", "the a an", "completely unrelated words here", "THE QUICK BROWN FOX", "dog lazy the over jumps fox brown quick the"]
+    cases = []
+    for o in base:
+        for t in variants:
+            cases.append({"original": o, "transcribed": t, "similarity": float(V.calculate_text_similarity(o, t))})
+    words = [("cat", "cut"), ("cat", "dog"), ("ab", "ab"), ("ab", "ac"), ("abc", "abd"), ("extraordinary", "extraordinarly"), ("extraordinary", "extraordinaire"),
+             ("hello", "help"), ("kitten", "sitting"), ("", "abc"), ("flaw", "lawn")]
+    out = {"pairs": cases,
+           "levenshtein": [{"a": a, "b": b, "distance": int(V._levenshtein_distance(a, b)), "fuzzy": bool(V._fuzzy_word_match(a, b))} for a, b in words],
+           "normalize": [{"text": x, "normalized": V._normalize_text(x)} for x in base + variants + ["Wait -- what?!  Co-operate; don't   stop.", "\tTabs\nand newlines "]],
+           "validate": [list(V.validate_audio_text_match.__defaults__)]}
+    with open(os.path.join(HERE, "textsim_golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", len(cases), "text-similarity pairs")
+
+
 def tone(n, f, amp=0.3, dc=0.0):
     i = np.arange(n, dtype=np.float64)
     return (amp * np.sin(2 * np.pi * f * i / SR) + dc).astype(np.float32)
@@ -284,6 +321,7 @@ def main():
 
     with open(os.path.join(HERE, "pipeline_golden.json"), "w") as f:
         json.dump(pipe, f, indent=1, sort_keys=True)
+    text_similarity_fixtures()
     print("wrote", len(out), "arrays and", len(pipe), "pipeline cases")
 
 
