@@ -280,9 +280,11 @@ def main():
 
 
 def cpu_baseline(cfg, args, eng):
-    """The CPU oracle (oracle/model.py, a port — the reference's own CPU path needs the absent qwen-tts package) timed on
-    this box's host cores on a bounded sample of the same workload: same model shape and batch, 2-s reference clip, 3 decoded
-    frames + their codec decode + post-processing.  Reported beside the GPU number, never as the target."""
+    """The CPU oracle (oracle/model.py, a port - the reference's own CPU path needs the absent qwen-tts package) timed on this
+    box's host cores on a BOUNDED sample of the same workload: same model shape, batch and prompt (30-s
+    reference clone, 460-row prefix, prefilled once and shared), 8 decoded frames per item + their codec decode + post-processing;
+    the per-frame costs are then extended linearly to the workload's frame count.  Reported beside the GPU number, never as the
+    target."""
     from oracle import postprocess as OP
     from oracle.model import OracleModel, Voice
     from oracle.sampling import SamplingParams
@@ -295,28 +297,39 @@ def cpu_baseline(cfg, args, eng):
     state = {k: v.cpu() for k, v in synthetic_state(cfg, 789, device=eng.device).items()}
     om = OracleModel(cfg, state)
     del state
-    B = args.batch if cfg.talker.hidden <= 1024 else min(args.batch, 32)
-    frames = 3
+    B = args.batch
+    frames = 8
+    full_frames = eng.frames_for(sentences(1, args.words, seed=789)[0], 0)
     texts = sentences(B, args.words, seed=789)
-    clip = synthetic_reference_clip(2.0, cfg.sample_rate, 789)
-    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode("time year people way day"), "english")
+    ref_words = 75 if args.ref_seconds >= 10 else max(3, int(args.ref_seconds * 2.5))
+    clip = synthetic_reference_clip(args.ref_seconds, cfg.sample_rate, 789)
+    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(" ".join(WORDS[i % len(WORDS)] for i in range(ref_words))), "english",
+                                   max_frames=cfg.max_positions // 2)
     v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
     ids = [eng.tokenizer.encode(t) for t in texts]
-    log("cpu baseline: oracle decode running ...")
+    log("cpu baseline: oracle prefill + decode running ...")
+    tm = {}
     t0 = time.perf_counter()
     with torch.no_grad():
-        codes = om.generate(v, ids, [frames] * B, SamplingParams(True, 0.9, 50, 1.0, 1.05), seed=789)
+        codes = om.generate(v, ids, [frames] * B, SamplingParams(True, 0.9, 50, 1.0, 1.05), seed=789, share_prefix=True, timing=tm)
+        t_dec = time.perf_counter()
         q = cfg.codec.num_quantizers
-        log(f"cpu baseline: decode done after {time.perf_counter() - t0:.1f} s, codec decoder ...")
+        log(f"cpu baseline: prefill {tm['prefill_done'] - t0:.1f} s, {frames} frames in {t_dec - tm['prefill_done']:.1f} s, codec decoder ...")
         wav = om.code2wav(torch.stack([c[:, :q].T for c in codes]))
+        t_voc = time.perf_counter()
         p = OP.PostParams(sample_rate=cfg.sample_rate)
         for b in range(B):
             OP.finish_item([wav[b]], p)
-    dt = time.perf_counter() - t0
-    audio_s = B * wav.shape[1] / cfg.sample_rate
-    return {"value": round(audio_s / dt, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/model.py (PyTorch eager f32 on bf16-valued weights), {cfg.name}, batch {B}, 2-s reference clip, "
-                      f"{frames} frames/item decoded + codec decode + post-processing, {dt:.1f} s of CPU work"}
+    t1 = time.perf_counter()
+    prefill, decode, vocode, post = tm["prefill_done"] - t0, t_dec - tm["prefill_done"], t_voc - t_dec, t1 - t_voc
+    scale = full_frames / frames
+    t_full = prefill + (decode + vocode + post) * scale
+    audio_full = B * om.wav_length(full_frames) / cfg.sample_rate
+    return {"value": round(audio_full / t_full, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/model.py (PyTorch eager f32 on bf16-valued weights), {cfg.name}, batch {B}, {args.ref_seconds:g}-s reference clone "
+                      f"({om.prefix_embeddings(v).shape[0]}-row prefix prefilled once), {frames} of {full_frames} frames/item decoded + codec decode + "
+                      f"post-processing = {t1 - t0:.1f} s of CPU work (prefill {prefill:.1f}, decode {decode:.1f}, codec {vocode:.1f}, post {post:.1f}); "
+                      f"value = the per-frame costs extended linearly to {full_frames} frames ({t_full:.0f} s)"}
 
 
 if __name__ == "__main__":

@@ -305,7 +305,7 @@ class OracleModel:
                  sp_talker: SamplingParams = SamplingParams(), sp_pred: Optional[SamplingParams] = None,
                  seed: int = 789, item_ids: Optional[Sequence[int]] = None, ignore_eos: bool = True,
                  min_frames: int = 2, forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: Optional[dict] = None,
-                 share_prefix: bool = False):
+                 share_prefix: bool = False, timing: Optional[dict] = None):
         """Autoregressive decode of a batch.  Returns a list of int64 code tensors [T_i, G].
 
         forced_codes: teacher forcing — the chosen codes of item b at frame t are taken from
@@ -356,6 +356,9 @@ class OracleModel:
         seen = np.zeros((B, c.codec_vocab), dtype=bool)
         out = [[] for _ in range(B)]
         done = [False] * B
+        if timing is not None:                      # bench.py's CPU baseline: prompt prefill vs per-frame decode
+            import time as _time
+            timing["prefill_done"] = _time.perf_counter()
         for t in range(T_max):
             logits = self.talker.head(xt, [self.W["talker.codec_head.weight"]], m_dec)[0]
             if trace is not None:
