@@ -58,6 +58,32 @@ class CodecDims:
     decoder_dim: int = 1536
     chunk_frames: int = 300
     left_context_frames: int = 25
+    # ---- encoder side (reference audio -> codes).  A SEANet-style causal conv encoder (filters x 2 per
+    # stage, strides enc_ratios), a pre-norm transformer at twice the frame rate, a stride-2 down-sampling conv and a split
+    # residual vector quantiser (1 semantic + num_quantizers - 1 acoustic codebooks) - the topology of the Mimi codec in the
+    # container's transformers (models/mimi/modeling_mimi.py), which the 12.5-Hz / 2048-entry / 16-codebook numbers match.
+    # UNVERIFIED against the real Qwen3-TTS tokenizer, like every other dimension here.
+    enc_filters: int = 64
+    enc_ratios: Tuple[int, ...] = (4, 5, 6, 8)
+    enc_kernel: int = 7
+    enc_res_kernel: int = 3
+    enc_last_kernel: int = 3
+    enc_hidden: int = 512
+    enc_layers: int = 8
+    enc_heads: int = 8
+    enc_head_dim: int = 64
+    enc_inter: int = 2048
+    enc_window: int = 250
+    vq_dim: int = 256
+    spk_hidden: int = 512            # speaker head: statistics pooling of the conv features -> fc -> talker width
+
+    @property
+    def enc_stride(self) -> int:
+        """Input samples per encoder frame (before the final stride-2 conv)."""
+        t = 1
+        for r in self.enc_ratios:
+            t *= r
+        return t
 
     @property
     def total_upsample(self) -> int:
@@ -115,8 +141,9 @@ class ModelConfig:
     def from_dict(d: dict) -> "ModelConfig":
         d = dict(d)
         talker, predictor, codec = TransformerDims(**d.pop("talker")), TransformerDims(**d.pop("predictor")), dict(d.pop("codec"))
-        for k in ("upsampling_ratios", "upsample_rates"):
-            codec[k] = tuple(codec[k])
+        for k in ("upsampling_ratios", "upsample_rates", "enc_ratios"):
+            if k in codec:
+                codec[k] = tuple(codec[k])
         d["role_ids"] = tuple(d["role_ids"])
         return ModelConfig(talker=talker, predictor=predictor, codec=CodecDims(**codec), **d)
 
@@ -147,7 +174,9 @@ def tiny(name: str = "tiny") -> ModelConfig:
         predictor=TransformerDims(hidden=64, layers=2, heads=2, kv_heads=1, head_dim=32, inter=128),
         codec=CodecDims(codebook_size=64, num_quantizers=4, hidden=64, layers=2, heads=2, head_dim=32, inter=128,
                         sliding_window=8, upsampling_ratios=(2,), upsample_rates=(3, 2), decoder_dim=64,
-                        chunk_frames=12, left_context_frames=3),
+                        chunk_frames=12, left_context_frames=3,
+                        enc_filters=16, enc_ratios=(2, 3), enc_hidden=32, enc_layers=2, enc_heads=2, enc_head_dim=32, enc_inter=64,
+                        enc_window=6, vq_dim=16, spk_hidden=32),
         codec_vocab=128, predictor_vocab=64, text_vocab=512, text_hidden=96, n_groups=4, max_positions=256,
         tts_pad_id=500, tts_bos_id=501, tts_eos_id=502, role_ids=(503, 504, 505),
         codec_pad_id=70, codec_bos_id=71, codec_eos_id=72, codec_think_id=73, codec_nothink_id=74,
@@ -164,7 +193,9 @@ def small(name: str = "small") -> ModelConfig:
         predictor=TransformerDims(hidden=256, layers=2, heads=4, kv_heads=2, head_dim=128, inter=512),
         codec=CodecDims(codebook_size=256, num_quantizers=8, hidden=256, layers=2, heads=4, head_dim=64, inter=512,
                         sliding_window=16, upsampling_ratios=(2, 2), upsample_rates=(4, 3, 2), decoder_dim=384,
-                        chunk_frames=24, left_context_frames=4),
+                        chunk_frames=24, left_context_frames=4,
+                        enc_filters=16, enc_ratios=(2, 4, 6), enc_hidden=128, enc_layers=2, enc_heads=4, enc_head_dim=32, enc_inter=256,
+                        enc_window=12, vq_dim=64, spk_hidden=64),
         codec_vocab=384, predictor_vocab=256, text_vocab=4096, text_hidden=320, n_groups=8, max_positions=1024,
         tts_pad_id=4000, tts_bos_id=4001, tts_eos_id=4002, role_ids=(4003, 4004, 4005),
         codec_pad_id=300, codec_bos_id=301, codec_eos_id=302, codec_think_id=303, codec_nothink_id=304,

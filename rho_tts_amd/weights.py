@@ -105,6 +105,44 @@ def tensor_specs(cfg: ModelConfig) -> List[Spec]:
     n = len(c.upsample_rates) + 1
     s += [(f"codec.decoder.{n}.alpha", (ch[-1],), "bias", 0.3), (f"codec.decoder.{n}.beta", (ch[-1],), "bias", 0.3),
           (f"codec.decoder.{n + 1}.conv.weight", (1, ch[-1], 7), "fan", 0.1), (f"codec.decoder.{n + 1}.conv.bias", (1,), "bias", 0.0)]
+    s += encoder_specs(cfg)
+    return s
+
+
+def encoder_transformer_dims(cfg: ModelConfig) -> TransformerDims:
+    c = cfg.codec
+    return TransformerDims(hidden=c.enc_hidden, layers=c.enc_layers, heads=c.enc_heads, kv_heads=c.enc_heads, head_dim=c.enc_head_dim,
+                           inter=c.enc_inter, rope_theta=c.rope_theta, rms_eps=c.rms_eps)
+
+
+def encoder_channels(cfg: ModelConfig) -> List[int]:
+    c = cfg.codec
+    return [c.enc_filters * (2 ** i) for i in range(len(c.enc_ratios) + 1)]
+
+
+def encoder_specs(cfg: ModelConfig) -> List[Spec]:
+    """Conditioning front-end: conv encoder -> transformer -> stride-2 conv -> split RVQ, and the speaker head.
+    ``enc.conv.{i}`` numbers the convolutions in execution order: 0 = input conv, then per stage [residual k3, residual k1,
+    strided], then the last conv."""
+    c = cfg.codec
+    ch = encoder_channels(cfg)
+    s: List[Spec] = [("enc.conv.0.weight", (ch[0], 1, c.enc_kernel), "fan", 1.0), ("enc.conv.0.bias", (ch[0],), "bias", 0.01)]
+    i = 1
+    for st, r in enumerate(c.enc_ratios):
+        d = ch[st]
+        s += [(f"enc.conv.{i}.weight", (d // 2, d, c.enc_res_kernel), "fan", 1.4), (f"enc.conv.{i}.bias", (d // 2,), "bias", 0.01),
+              (f"enc.conv.{i + 1}.weight", (d, d // 2, 1), "fan", 1.4), (f"enc.conv.{i + 1}.bias", (d,), "bias", 0.01),
+              (f"enc.conv.{i + 2}.weight", (2 * d, d, 2 * r), "fan", 1.4), (f"enc.conv.{i + 2}.bias", (2 * d,), "bias", 0.01)]
+        i += 3
+    s += [(f"enc.conv.{i}.weight", (c.enc_hidden, ch[-1], c.enc_last_kernel), "fan", 1.4), (f"enc.conv.{i}.bias", (c.enc_hidden,), "bias", 0.01)]
+    s += _layer_specs("enc.transformer", encoder_transformer_dims(cfg), 0.02, layer_scale=True, qk_norm=False)
+    s += [("enc.downsample.weight", (c.enc_hidden, c.enc_hidden, 4), "fan", 1.0)]
+    s += [("enc.vq.semantic.input_proj.weight", (c.vq_dim, c.enc_hidden), "fan", 1.0),
+          ("enc.vq.acoustic.input_proj.weight", (c.vq_dim, c.enc_hidden), "fan", 1.0)]
+    for q in range(c.num_quantizers):
+        s.append((f"enc.vq.codebook.{q}", (c.codebook_size, c.vq_dim), "mat", 0.6 * (0.8 ** min(q, 8))))
+    s += [("enc.spk.fc1.weight", (c.spk_hidden, 2 * c.enc_hidden), "fan", 1.0), ("enc.spk.fc1.bias", (c.spk_hidden,), "bias", 0.01),
+          ("enc.spk.fc2.weight", (cfg.talker.hidden, c.spk_hidden), "fan", 0.4), ("enc.spk.fc2.bias", (cfg.talker.hidden,), "bias", 0.01)]
     return s
 
 
