@@ -36,7 +36,7 @@ extern "C" {
 
 #define RT_API __attribute__((visibility("default")))
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -157,6 +157,16 @@ typedef struct rt_stack_dims {
     float rope_theta, rms_eps;
 } rt_stack_dims;
 
+/* Conditioning front-end (reference audio -> codes + speaker embedding): a causal conv encoder (filters x 2 per stage,
+ * strides ratios[]), a transformer at twice the frame rate, a stride-2 conv and a split residual vector quantiser.
+ * filters = 0: the model has no encoder (rt_voice_encode / rt_model_set_voice_pcm return RT_ERR_UNSUPPORTED). */
+typedef struct rt_encoder_config {
+    int32_t filters, n_ratios, ratios[8], kernel, res_kernel, last_kernel;
+    rt_stack_dims tf;             /* hidden = encoder width                                  */
+    int32_t window, vq_dim, spk_hidden;
+    int32_t max_ref_frames;       /* longest reference clip, in codec frames                  */
+} rt_encoder_config;
+
 typedef struct rt_model_config {
     rt_stack_dims talker, predictor, codec_tf;
     int32_t codec_vocab, predictor_vocab, text_vocab, text_hidden, n_groups;
@@ -171,6 +181,7 @@ typedef struct rt_model_config {
     int32_t max_positions;        /* KV rows per sequence (prompt + frames) */
     int32_t max_codec_frames;     /* frames per sequence one rt_code2wav call may decode */
     int32_t reserved[4];
+    rt_encoder_config enc;
 } rt_model_config;
 
 #define RT_DTYPE_BF16 0
@@ -206,6 +217,20 @@ RT_API int64_t rt_model_weight_bytes(rt_model* m);
  */
 RT_API int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids,
                               int32_t h_speaker_row, const float* h_speaker_embed);
+/* The step BEFORE the path: the reference hands the model a reference-audio PATH on every call
+ * (ref_audio=..., providers/qwen.py:253-258) and the model encodes it each time; here the clip is encoded once, on the GPU.
+ *   h_pcm       mono float32 in [-1, 1] at the model's sample rate (host memory); n_samples is cut down to whole codec frames
+ *   h_codes     out [n_frames][num_quantizers] (capacity max_frames rows), h_n_frames out
+ *   h_speaker_embed  out [talker hidden] float32 (statistics-pooled speaker head), may be NULL */
+RT_API int rt_voice_encode(rt_model* m, const float* h_pcm, int64_t n_samples, int32_t* h_codes, int32_t max_frames, int32_t* h_n_frames,
+                           float* h_speaker_embed);
+/* rt_voice_encode + rt_model_set_voice in one call: the recipe arrays describe the rows BEFORE the reference frames (role /
+ * control / speaker / bos / reference-text rows, as for rt_model_set_voice); one row per encoded frame is appended, with text id
+ * frame_text_id (tts_pad) and the frame's codes; the speaker row receives the encoder's speaker embedding.  Needs
+ * num_quantizers == n_groups.  h_codes / h_n_frames (optional) return what was encoded. */
+RT_API int rt_model_set_voice_pcm(rt_model* m, const float* h_pcm, int64_t n_samples, int32_t n_head_rows, const int32_t* h_text_ids,
+                                  const int32_t* h_codec_ids, int32_t h_speaker_row, int32_t frame_text_id, int32_t max_ref_frames,
+                                  int32_t* h_codes, int32_t* h_n_frames);
 RT_API int32_t rt_voice_prefix_len(rt_model* m);
 /* Prefix KV as one HBM blob [2][layers][kv_heads][prefix_len][head_dim] bf16, for an RCCL broadcast. */
 RT_API int64_t rt_voice_blob_bytes(rt_model* m);

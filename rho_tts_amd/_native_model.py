@@ -8,7 +8,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .config import ModelConfig, TransformerDims
-from .weights import codec_transformer_dims, decoder_channels
+from .weights import codec_transformer_dims, decoder_channels, encoder_transformer_dims
 
 DT_BF16, DT_F32 = 0, 1
 
@@ -18,6 +18,12 @@ class StackDims(C.Structure):
                 ("head_dim", C.c_int32), ("inter", C.c_int32), ("rope_theta", C.c_float), ("rms_eps", C.c_float)]
 
 
+class RtEncoderConfig(C.Structure):
+    _fields_ = [("filters", C.c_int32), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("kernel", C.c_int32), ("res_kernel", C.c_int32),
+                ("last_kernel", C.c_int32), ("tf", StackDims), ("window", C.c_int32), ("vq_dim", C.c_int32), ("spk_hidden", C.c_int32),
+                ("max_ref_frames", C.c_int32)]
+
+
 class RtModelConfig(C.Structure):
     _fields_ = [("talker", StackDims), ("predictor", StackDims), ("codec_tf", StackDims),
                 ("codec_vocab", C.c_int32), ("predictor_vocab", C.c_int32), ("text_vocab", C.c_int32),
@@ -25,7 +31,7 @@ class RtModelConfig(C.Structure):
                 ("num_quantizers", C.c_int32), ("codec_sliding_window", C.c_int32), ("n_upsampling", C.c_int32),
                 ("upsampling_ratios", C.c_int32 * 4), ("n_upsample_rates", C.c_int32), ("upsample_rates", C.c_int32 * 8),
                 ("decoder_dim", C.c_int32), ("codec_eos_id", C.c_int32), ("max_batch", C.c_int32),
-                ("max_positions", C.c_int32), ("max_codec_frames", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("max_positions", C.c_int32), ("max_codec_frames", C.c_int32), ("reserved", C.c_int32 * 4), ("enc", RtEncoderConfig)]
 
 
 class RtSampling(C.Structure):
@@ -54,6 +60,8 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_model_weight_bytes.restype = i64
     lib.rt_model_weight_bytes.argtypes = [vp]
     lib.rt_model_set_voice.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(C.c_float)]
+    lib.rt_voice_encode.argtypes = [vp, C.POINTER(C.c_float), i64, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_float)]
+    lib.rt_model_set_voice_pcm.argtypes = [vp, C.POINTER(C.c_float), i64, i32, C.POINTER(i32), C.POINTER(i32), i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.rt_voice_prefix_len.argtypes = [vp]
     lib.rt_voice_blob_bytes.restype = i64
     lib.rt_voice_blob_bytes.argtypes = [vp]
@@ -93,6 +101,14 @@ def rt_config(cfg: ModelConfig, max_batch: int, max_positions: int, max_codec_fr
     c.decoder_dim = cfg.codec.decoder_dim
     c.codec_eos_id = cfg.codec_eos_id
     c.max_batch, c.max_positions, c.max_codec_frames = max_batch, max_positions, max_codec_frames
+    e, k = c.enc, cfg.codec
+    e.filters, e.n_ratios = k.enc_filters, len(k.enc_ratios)
+    for i, r in enumerate(k.enc_ratios):
+        e.ratios[i] = r
+    e.kernel, e.res_kernel, e.last_kernel = k.enc_kernel, k.enc_res_kernel, k.enc_last_kernel
+    e.tf = _stack(encoder_transformer_dims(cfg))
+    e.window, e.vq_dim, e.spk_hidden = k.enc_window, k.vq_dim, k.spk_hidden
+    e.max_ref_frames = max(1, max_positions // 2)          # a reference clip may take half of the KV rows (Engine.set_voice_from_audio)
     return c
 
 
@@ -201,6 +217,21 @@ def to_native(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str, tor
     out["codec.fin_w"] = conv_mat(state[f"codec.decoder.{n + 1}.conv.weight"])                  # [1, 7*C]
     out["codec.fin_wv"] = f32(out["codec.fin_w"]).reshape(-1)                                     # the same taps as a plain vector
     out["codec.fin_b"] = f32(state[f"codec.decoder.{n + 1}.conv.bias"])
+    # ---- conditioning front-end (every conv, strided ones included, is [Co][k*Ci] with column = tap*Ci + ci: a k = 2r, stride r
+    # conv over [T][Ci] is the 2-tap conv over the clip viewed as [T/r][r*Ci], whose column order is the same)
+    out["enc.conv0_w"] = f32(state["enc.conv.0.weight"][:, 0, :]).reshape(-1)
+    out["enc.conv0_b"] = f32(state["enc.conv.0.bias"])
+    for i in range(1, 2 + 3 * len(c.enc_ratios)):
+        out[f"enc.c{i}"] = conv_mat(state[f"enc.conv.{i}.weight"])
+        out[f"enc.c{i}_b"] = f32(state[f"enc.conv.{i}.bias"])
+    stack("enc.transformer", "etf", encoder_transformer_dims(cfg), False, True)
+    out["enc.down"] = conv_mat(state["enc.downsample.weight"])
+    out["enc.vq_sem"] = state["enc.vq.semantic.input_proj.weight"].to(bf).contiguous()
+    out["enc.vq_aco"] = state["enc.vq.acoustic.input_proj.weight"].to(bf).contiguous()
+    for q in range(c.num_quantizers):
+        out[f"enc.cbT{q}"] = f32(state[f"enc.vq.codebook.{q}"]).t().contiguous().reshape(-1)      # [D][K]: entries contiguous per dimension
+    out["enc.spk_fc1"], out["enc.spk_fc1_b"] = f32(state["enc.spk.fc1.weight"]).reshape(-1), f32(state["enc.spk.fc1.bias"])
+    out["enc.spk_fc2"], out["enc.spk_fc2_b"] = f32(state["enc.spk.fc2.weight"]).reshape(-1), f32(state["enc.spk.fc2.bias"])
     return out
 
 
@@ -325,6 +356,38 @@ class NativeModel:
             emb = (C.c_float * e.numel())(*e.tolist())
         self.ctx.check(self.lib.rt_model_set_voice(self.handle, n, t_arr, c_arr, spk_row, emb), "rt_model_set_voice")
         return n
+
+    # ------------------------------------------------------------------ conditioning front-end
+    def encode_voice(self, pcm, max_frames: Optional[int] = None):
+        """Reference audio (1-D float32 at cfg.sample_rate, host) -> (codes [T, num_quantizers] int64, speaker embedding [hidden])."""
+        import numpy as np
+        x = np.ascontiguousarray(np.asarray(pcm, dtype=np.float32).reshape(-1))
+        cap = int(max_frames or self.rt_cfg.enc.max_ref_frames)
+        Q = self.cfg.codec.num_quantizers
+        codes = (C.c_int32 * (cap * Q))()
+        nf = C.c_int32()
+        spk = (C.c_float * self.cfg.talker.hidden)()
+        rc = self.lib.rt_voice_encode(self.handle, x.ctypes.data_as(C.POINTER(C.c_float)), x.size, codes, cap, C.byref(nf), spk)
+        self.ctx.check(rc, "rt_voice_encode")
+        out = torch.tensor(list(codes[: nf.value * Q]), dtype=torch.int64).reshape(nf.value, Q)
+        return out, torch.tensor(list(spk), dtype=torch.float32)
+
+    def set_voice_pcm(self, pcm, language="english", ref_text_ids=(), max_frames: Optional[int] = None):
+        """rt_model_set_voice_pcm: encode the clip and install the voice prefix in one call.  Returns (prefix rows, codes)."""
+        import numpy as np
+        x = np.ascontiguousarray(np.asarray(pcm, dtype=np.float32).reshape(-1))
+        G = self.cfg.n_groups
+        one = torch.zeros(1, G, dtype=torch.int64)
+        text, codec, spk_row = self.prefix_recipe(language, None, torch.zeros(self.cfg.talker.hidden), ref_text_ids, one)
+        text, codec = text[:-1], codec[:-1]                    # the recipe's head: everything before the reference frames
+        n = len(text)
+        cap = int(max_frames or self.rt_cfg.enc.max_ref_frames)
+        codes = (C.c_int32 * (cap * G))()
+        nf = C.c_int32()
+        rc = self.lib.rt_model_set_voice_pcm(self.handle, x.ctypes.data_as(C.POINTER(C.c_float)), x.size, n, (C.c_int32 * n)(*text),
+                                             (C.c_int32 * (n * G))(*[v for r in codec for v in r]), spk_row, self.cfg.tts_pad_id, cap, codes, C.byref(nf))
+        self.ctx.check(rc, "rt_model_set_voice_pcm")
+        return n + nf.value, torch.tensor(list(codes[: nf.value * G]), dtype=torch.int64).reshape(nf.value, G)
 
     def prefix_len(self) -> int:
         return int(self.lib.rt_voice_prefix_len(self.handle))

@@ -1,0 +1,157 @@
+// Kernels of the conditioning front-end (reference audio -> codec codes + speaker embedding).  The convolutions
+// and projections of the encoder run on the tiled MFMA GEMM (gemm.hip) in split precision; this file holds what is not a GEMM:
+// the 1-channel input conv, the residual vector quantiser, the statistics pooling and the speaker head's matrix-vector products.
+// Built with -ffp-contract=off: the quantiser's distance has a DEFINED float32 evaluation order (oracle/encoder.py rvq_level)
+// and its argmin is compared bit for bit.
+#include "kernels.h"
+
+namespace {
+
+// x[t][c] = b[c] + sum_k w[c][k] * pcm[t - (K - 1) + k]   (zeros before the clip); 256 threads = 256 / C time steps x C channels
+__global__ __launch_bounds__(256) void k_enc_conv0(const float* __restrict__ pcm, int64_t T, int C, int K, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ x, bf16_t* __restrict__ hi,
+                                                   bf16_t* __restrict__ lo) {
+    const int c = threadIdx.x % C, tl = threadIdx.x / C, per = blockDim.x / C;
+    for (int64_t t = (int64_t)blockIdx.x * per + tl; t < T; t += (int64_t)gridDim.x * per) {
+        float acc = bias[c];
+        for (int k = 0; k < K; ++k) {
+            const int64_t ti = t - (K - 1) + k;
+            if (ti >= 0) acc += w[c * K + k] * pcm[ti];
+        }
+        const int64_t o = t * C + c;
+        x[o] = acc;
+        const float e = acc > 0.f ? acc : expm1f(acc);
+        const bf16_t h = f32_to_bf16(e);
+        hi[o] = h;
+        lo[o] = f32_to_bf16(e - bf16_to_f32(h));
+    }
+}
+
+// One workgroup per frame walks the quantiser levels: distances of the current vector to all K entries of the level's
+// codebook (transposed [D][K]: at step k the threads read consecutive entries), argmin with the lowest index on ties,
+// residual update.  Level 0 quantises the semantic projection, levels 1.. the acoustic projection residually.
+constexpr int RVQ_T = 256, RVQ_MAXE = 16;        // entries per thread: K <= 4096
+__global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, float* __restrict__ aco, int D, int K, int Q,
+                                               const float* const* __restrict__ cbT, int32_t* __restrict__ codes) {
+    extern __shared__ float sh_x[];              // [D]
+    __shared__ float sh_d[RVQ_T];
+    __shared__ int sh_j[RVQ_T];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int ne = (K + RVQ_T - 1) / RVQ_T;
+    for (int q = 0; q < Q; ++q) {
+        if (q <= 1) {                             // level 0: semantic vector; level 1: (fresh) acoustic vector; later: residual already in LDS
+            const float* src = (q == 0 ? sem : aco) + (int64_t)t * D;
+            __syncthreads();
+            for (int k = tid; k < D; k += RVQ_T) sh_x[k] = src[k];
+        }
+        __syncthreads();
+        const float* cb = cbT[q];
+        float acc[RVQ_MAXE];
+#pragma unroll
+        for (int i = 0; i < RVQ_MAXE; ++i) acc[i] = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float xv = sh_x[k];
+            const float* row = cb + (int64_t)k * K;
+#pragma unroll
+            for (int i = 0; i < RVQ_MAXE; ++i) {
+                const int j = tid + i * RVQ_T;
+                if (i < ne && j < K) {
+                    const float diff = xv - row[j];
+                    acc[i] = acc[i] + diff * diff;             // (no contraction: see the file header)
+                }
+            }
+        }
+        float best = 3.4e38f;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < RVQ_MAXE; ++i) {
+            const int j = tid + i * RVQ_T;
+            if (i < ne && j < K && acc[i] < best) { best = acc[i]; bj = j; }      // ascending j inside a thread: strict <
+        }
+        sh_d[tid] = best;
+        sh_j[tid] = bj;
+        __syncthreads();
+        for (int s = RVQ_T / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                const float d2 = sh_d[tid + s];
+                const int j2 = sh_j[tid + s];
+                if (d2 < sh_d[tid] || (d2 == sh_d[tid] && j2 < sh_j[tid])) { sh_d[tid] = d2; sh_j[tid] = j2; }
+            }
+            __syncthreads();
+        }
+        const int win = sh_j[0];
+        if (tid == 0) codes[(int64_t)t * Q + q] = win;
+        if (q >= 1) {                             // residual for the next acoustic level
+            for (int k = tid; k < D; k += RVQ_T) sh_x[k] = sh_x[k] - cb[(int64_t)k * K + win];
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < D; k += RVQ_T) aco[(int64_t)t * D + k] = sh_x[k];
+}
+
+// one workgroup per 64 channels; threads = 4 time lanes x 64 channels, two passes (mean, then variance about it)
+__global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ x, int T, int C, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < C) for (int t = tl; t < T; t += 4) s += x[(int64_t)t * C + c];
+    sh[tl][cl] = s;
+    __syncthreads();
+    const float mean = (sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)T;
+    __syncthreads();
+    float v = 0.f;
+    if (c < C) for (int t = tl; t < T; t += 4) { const float d = x[(int64_t)t * C + c] - mean; v += d * d; }
+    sh[tl][cl] = v;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        out[c] = mean;
+        out[C + c] = sqrtf((sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]) / (float)T + 1e-5f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gemv_f32(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ x, int N,
+                                                  int K, int relu, float* __restrict__ y) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += W[(int64_t)n * K + k] * x[k];
+    s = wave_sum_f32(s);
+    if (lane == 0) {
+        s += b ? b[n] : 0.f;
+        y[n] = relu ? fmaxf(s, 0.f) : s;
+    }
+}
+
+}  // namespace
+
+int launch_enc_conv0(rt_ctx* ctx, const float* pcm, int64_t T, int C, int k, const float* w, const float* bias, float* x, bf16_t* hi, bf16_t* lo) {
+    if (T <= 0) return RT_OK;
+    if (C < 1 || C > 256 || 256 % C) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "encoder: first-conv width %d must divide 256", C);
+    const int per = 256 / C;
+    int64_t blocks = (T + per - 1) / per;
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    hipLaunchKernelGGL(k_enc_conv0, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, pcm, T, C, k, w, bias, x, hi, lo);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_rvq(rt_ctx* ctx, const float* sem, float* aco, int T, int D, int K, int Q, const float* const* d_cbT, int32_t* codes) {
+    if (T <= 0) return RT_OK;
+    if (K > RVQ_T * RVQ_MAXE || D > 4096 || Q < 1) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rvq: codebook of %d entries x %d (max %d x 4096)", K, D, RVQ_T * RVQ_MAXE);
+    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(RVQ_T), (size_t)D * 4, ctx->stream, sem, aco, D, K, Q, d_cbT, codes);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_stats_pool(rt_ctx* ctx, const float* x, int T, int C, float* out) {
+    if (T <= 0) return rt_fail(ctx, RT_ERR_INVALID, "stats_pool: empty input");
+    hipLaunchKernelGGL(k_stats_pool, dim3((C + 63) / 64), dim3(256), 0, ctx->stream, x, T, C, out);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_gemv_f32(rt_ctx* ctx, const float* W, const float* b, const float* x, int N, int K, int relu, float* y) {
+    hipLaunchKernelGGL(k_gemv_f32, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, W, b, x, N, K, relu, y);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}

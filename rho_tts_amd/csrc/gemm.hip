@@ -273,6 +273,9 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
             } else if (e.act == ACT_CLAMP1) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = fminf(1.f, fmaxf(-1.f, v[i]));
+            } else if (e.act == ACT_ELU) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
             }
             if (e.scale) {
                 const float scale = e.scale[n];
@@ -300,9 +303,14 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
                 }
             }
             if (e.out2_hi || e.out2_bf16 || e.out2_f32) {
-                const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+                if (e.act2 == ACT_ELU) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
+                    for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
+                } else {
+                    const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
+                }
                 if (e.out2_hi) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -765,7 +773,8 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     g.xcd_order = (g_xcd_order && e.split_k == 1 && ny > 1 && my >= 64) ? 1 : 0;
     dim3 grid((unsigned)(g.xcd_order ? (my + 7) / 8 * 8 : my), ny, e.split_k);
     if (a.split && !a.is_f32 && !a.ptr_lo) return rt_fail(ctx, RT_ERR_INVALID, "gemm: split precision needs an f32 A operand or a low plane");
-    if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || !e.snake2_a || !e.snake2_ib)) || ((e.out_hi || e.out2_hi) && e.split_k > 1))
+    if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || (e.act2 != ACT_ELU && (!e.snake2_a || !e.snake2_ib)))) ||
+        ((e.out_hi || e.out2_hi) && e.split_k > 1))
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");
     // codec decoder k>1 convs on operand planes: input window in LDS (k_conv_win)
     if (g_conv_win && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 && a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out &&

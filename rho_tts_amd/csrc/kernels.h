@@ -36,7 +36,7 @@ struct GemmA {
     int rows_in = 0;       // input rows per batch item
 };
 
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SNAKE = 3, ACT_CLAMP1 = 4 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_SNAKE = 3, ACT_CLAMP1 = 4, ACT_ELU = 5 };
 
 // out = (act(acc + bias)) * scale + residual, optionally also out2 = snake2(out) in bf16.
 // All per-column vectors have length N.  With split_k > 1 only raw f32 partial slabs are written
@@ -58,6 +58,7 @@ struct GemmEpi {
     bf16_t* out2_lo = nullptr;
     const float* snake2_a = nullptr;
     const float* snake2_ib = nullptr;
+    int act2 = ACT_SNAKE;                // what out2 applies to out: ACT_SNAKE (snake2_a / snake2_ib) or ACT_ELU
     int64_t ldc = 0;
     int split_k = 1;
 };
@@ -245,3 +246,15 @@ int launch_code_embed_mean(rt_ctx* ctx, const bf16_t* table, int codebook, int Q
 bool launch_final_conv_ok(int C);
 int launch_final_conv(rt_ctx* ctx, const bf16_t* hi, const bf16_t* lo, int B, int T, int C, const float* w, const float* bias, float* wav);
 int launch_f32_to_bf16(rt_ctx* ctx, const float* x, int64_t n, bf16_t* out);
+
+// ------------------------------------------------------------------------------ conditioning front-end (encoder.hip)
+// first conv of the audio encoder (1 -> C channels, k taps, causal): pcm [T] -> x [T][C] f32 and ELU(x) as hi / lo bf16 planes
+int launch_enc_conv0(rt_ctx* ctx, const float* pcm, int64_t T, int C, int k, const float* w /*[C][k]*/, const float* bias, float* x,
+                     bf16_t* hi, bf16_t* lo);
+// split residual vector quantiser: sem / aco [T][D] f32 (aco is consumed: it holds the final residual afterwards),
+// codebooks transposed [Q][D][K] f32 -> codes [T][Q]; fixed evaluation order (oracle/encoder.py rvq_level), lowest index on ties
+int launch_rvq(rt_ctx* ctx, const float* sem, float* aco, int T, int D, int K, int Q, const float* const* d_cbT, int32_t* codes);
+// statistics pooling over time: x [T][C] -> out [2C] = (mean, sqrt(var + 1e-5))
+int launch_stats_pool(rt_ctx* ctx, const float* x, int T, int C, float* out);
+// y [N] = act(W [N][K] x [K] + b): f32 weights, one wave per output
+int launch_gemv_f32(rt_ctx* ctx, const float* W, const float* b, const float* x, int N, int K, int relu, float* y);

@@ -75,7 +75,9 @@ struct rt_model {
     std::vector<Slot> slots;
     std::map<std::string, int> by_name;
     bool finalized = false;
-    StackW talker, pred, ctf;
+    StackW talker, pred, ctf, etf;     // etf: the audio encoder's transformer (conditioning front-end)
+    std::vector<int> enc_ch;           // encoder channel ladder
+    const float** d_cbT = nullptr;     // device array of the transposed codebooks
     std::vector<int> dec_ch;  // decoder channel ladder
     // derived tables
     float* pad_t = nullptr;   // text_proj(tts_pad)  [H]  (computed on first use)
@@ -233,6 +235,36 @@ void declare_slots(rt_model* m) {
     add_slot(m, "codec.fin_w", K_GEMM, 1, 7 * (int64_t)cl);   // last conv (C -> 1, k = 7) as a one-column GEMM
     add_slot(m, "codec.fin_wv", K_VEC, 7 * (int64_t)cl, 1);  // ... and as a plain f32 vector for the dedicated last-conv kernel
     add_slot(m, "codec.fin_b", K_VEC, 1, 1);
+    // ---- conditioning front-end (optional)
+    const rt_encoder_config& e = c.enc;
+    if (e.filters > 0) {
+        m->enc_ch.clear();
+        for (int i = 0; i <= e.n_ratios; ++i) m->enc_ch.push_back(e.filters << i);
+        add_slot(m, "enc.conv0_w", K_VEC, (int64_t)e.filters * e.kernel, 1);
+        add_slot(m, "enc.conv0_b", K_VEC, e.filters, 1);
+        int ci = 1;
+        auto conv = [&](int co, int cin, int k) {
+            add_slot(m, "enc.c" + std::to_string(ci), K_GEMM, co, (int64_t)k * cin);
+            add_slot(m, "enc.c" + std::to_string(ci) + "_b", K_VEC, co, 1);
+            ++ci;
+        };
+        for (int st = 0; st < e.n_ratios; ++st) {
+            const int d = m->enc_ch[st];
+            conv(d / 2, d, e.res_kernel);
+            conv(d, d / 2, 1);
+            conv(2 * d, d, 2 * e.ratios[st]);
+        }
+        conv(e.tf.hidden, m->enc_ch.back(), e.last_kernel);
+        add_stack_slots(m, "etf", e.tf, false, true);
+        add_slot(m, "enc.down", K_GEMM, e.tf.hidden, 4 * (int64_t)e.tf.hidden);
+        add_slot(m, "enc.vq_sem", K_GEMM, e.vq_dim, e.tf.hidden);
+        add_slot(m, "enc.vq_aco", K_GEMM, e.vq_dim, e.tf.hidden);
+        for (int q = 0; q < c.num_quantizers; ++q) add_slot(m, "enc.cbT" + std::to_string(q), K_VEC, (int64_t)e.vq_dim * c.codebook_size, 1);
+        add_slot(m, "enc.spk_fc1", K_VEC, (int64_t)e.spk_hidden * 2 * e.tf.hidden, 1);
+        add_slot(m, "enc.spk_fc1_b", K_VEC, e.spk_hidden, 1);
+        add_slot(m, "enc.spk_fc2", K_VEC, (int64_t)c.talker.hidden * e.spk_hidden, 1);
+        add_slot(m, "enc.spk_fc2_b", K_VEC, c.talker.hidden, 1);
+    }
 }
 
 const PackedW& PW(rt_model* m, const std::string& n) { return find_slot(m, n)->pw; }
@@ -537,6 +569,14 @@ int rt_model_create(rt_ctx* ctx, const rt_model_config* cfg, rt_model** out_mode
         c.n_upsampling < 0 || c.n_upsampling > 4 || c.n_upsample_rates < 1 || c.n_upsample_rates > 8 || c.text_hidden % 16 ||
         c.max_positions < 8 || c.max_codec_frames < 1 || (c.decoder_dim >> c.n_upsample_rates) < 8 || (c.decoder_dim >> c.n_upsample_rates) % 8)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_model_create: unsupported configuration (n_groups 2..32, max_batch 1..64, channels %% 8)");
+    if (c.enc.filters > 0) {
+        const rt_encoder_config& e = c.enc;
+        bool bad = e.n_ratios < 1 || e.n_ratios > 8 || e.filters % 16 || 256 % e.filters || e.kernel < 1 || e.kernel > 15 || e.res_kernel < 1 ||
+                   e.last_kernel < 1 || bad_stack(e.tf) || e.vq_dim % 8 || e.vq_dim > 4096 || c.codebook_size > 4096 || e.spk_hidden < 1 ||
+                   e.max_ref_frames < 1 || e.window < 1;
+        for (int i = 0; i < e.n_ratios && !bad; ++i) bad = e.ratios[i] < 1;
+        if (bad) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_create: unsupported encoder configuration (filters %% 16, filters | 256, vq_dim %% 8)");
+    }
     std::lock_guard<std::mutex> g(ctx->mu);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rt_model* m = new rt_model();
@@ -554,7 +594,8 @@ int rt_model_destroy(rt_model* m) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& s : m->slots) { if (s.raw) (void)hipFree(s.raw); if (s.raw16) (void)hipFree(s.raw16); }
-    for (StackW* S : {&m->talker, &m->pred, &m->ctf}) {
+    if (m->d_cbT) (void)hipFree((void*)m->d_cbT);
+    for (StackW* S : {&m->talker, &m->pred, &m->ctf, &m->etf}) {
         if (S->kv.k) (void)hipFree(S->kv.k);
         if (S->kv.v) (void)hipFree(S->kv.v);
         if (S->kv.k_lo) (void)hipFree(S->kv.k_lo);
@@ -662,6 +703,26 @@ int rt_model_finalize(rt_model* m, const float* h_rope_cos[3], const float* h_ro
         RT_HIP(ctx, hipMemcpy(S.cos, h_rope_cos[i], n * 4, hipMemcpyHostToDevice));
         RT_HIP(ctx, hipMemcpy(S.sin, h_rope_sin[i], n * 4, hipMemcpyHostToDevice));
     }
+    if (c.enc.filters > 0) {
+        // the encoder's transformer runs at twice the frame rate; its RoPE table is computed here, in float32 and in the order
+        // the host-side tables use (inv = 1 / theta^(2i/d); angle = pos * inv)
+        const rt_encoder_config& e = c.enc;
+        RT_TRY(bind_stack(m, m->etf, "etf", e.tf, 1, 2 * e.max_ref_frames, e.window, true));
+        const int half = e.tf.head_dim / 2, npos = 2 * e.max_ref_frames;
+        std::vector<float> hc((size_t)npos * half), hs((size_t)npos * half);
+        for (int i = 0; i < half; ++i) {
+            const float inv = 1.0f / powf(e.tf.rope_theta, (float)(2 * i) / (float)e.tf.head_dim);
+            for (int p = 0; p < npos; ++p) { const float a = (float)p * inv; hc[(size_t)p * half + i] = cosf(a); hs[(size_t)p * half + i] = sinf(a); }
+        }
+        RT_HIP(ctx, hipMalloc((void**)&m->etf.cos, hc.size() * 4));
+        RT_HIP(ctx, hipMalloc((void**)&m->etf.sin, hs.size() * 4));
+        RT_HIP(ctx, hipMemcpy(m->etf.cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+        RT_HIP(ctx, hipMemcpy(m->etf.sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+        std::vector<const float*> cbs(c.num_quantizers);
+        for (int q = 0; q < c.num_quantizers; ++q) cbs[q] = VEC(m, "enc.cbT" + std::to_string(q));
+        RT_HIP(ctx, hipMalloc((void**)&m->d_cbT, sizeof(float*) * c.num_quantizers));
+        RT_HIP(ctx, hipMemcpy((void*)m->d_cbT, cbs.data(), sizeof(float*) * c.num_quantizers, hipMemcpyHostToDevice));
+    }
     // frame-embedding sources: group 0 = talker codec table, group g = predictor table g-1
     std::vector<GatherSrc> srcs(c.n_groups);
     srcs[0] = {TBL(m, "talker.codec_embedding"), c.talker.hidden};
@@ -724,12 +785,10 @@ int rt_profile_read(rt_model* m, int64_t* n_launches, double* total_ms, double* 
 }
 
 // ------------------------------------------------------------------------------------------ voice
-int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids, int32_t h_speaker_row,
-                       const float* h_speaker_embed) {
-    if (!m || n_rows < 1 || !h_text_ids || !h_codec_ids) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_set_voice: null argument");
+// (the context mutex is held by the caller)
+static int set_voice_impl(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids, int32_t h_speaker_row,
+                          const float* h_speaker_embed) {
     rt_ctx* ctx = m->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_model_set_voice: model not finalized");
     const rt_model_config& c = m->cfg;
     if (n_rows + 8 > c.max_positions) return rt_fail(ctx, RT_ERR_LENGTH, "voice prefix length %d exceeds max_positions %d", n_rows, c.max_positions);
@@ -777,6 +836,175 @@ int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, c
     m->prefix_len = n_rows;
     pool_release_all(m);
     return RT_OK;
+}
+
+int rt_model_set_voice(rt_model* m, int32_t n_rows, const int32_t* h_text_ids, const int32_t* h_codec_ids, int32_t h_speaker_row,
+                       const float* h_speaker_embed) {
+    if (!m || n_rows < 1 || !h_text_ids || !h_codec_ids) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_set_voice: null argument");
+    std::lock_guard<std::mutex> g(m->ctx->mu);
+    RT_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    return set_voice_impl(m, n_rows, h_text_ids, h_codec_ids, h_speaker_row, h_speaker_embed);
+}
+
+// ---- conditioning front-end: reference audio -> codes [frames][num_quantizers] + speaker embedding (mutex held by the caller).
+// Channels-last activations; every convolution is an implicit GEMM in split precision (float32 activations fed as hi + lo bf16
+// planes): a k = 2r, stride r conv is the 2-tap GEMM over the clip viewed as [T / r][r * C] rows (causal: taps at t - 1 and t).
+static int voice_encode_impl(rt_model* m, const float* h_pcm, int64_t n_samples, int32_t* h_codes, int32_t max_frames, int32_t* h_n_frames,
+                             float* h_speaker_embed) {
+    rt_ctx* ctx = m->ctx;
+    const rt_model_config& c = m->cfg;
+    const rt_encoder_config& e = c.enc;
+    if (e.filters <= 0) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "this model was created without an audio encoder (rt_model_config.enc)");
+    if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_voice_encode: model not finalized");
+    int64_t hop = 2;
+    for (int i = 0; i < e.n_ratios; ++i) hop *= e.ratios[i];
+    const int64_t n_frames = std::min<int64_t>(std::min<int64_t>(n_samples / hop, max_frames), e.max_ref_frames);
+    if (n_frames < 1) return rt_fail(ctx, RT_ERR_INVALID, "reference audio is shorter than one codec frame (%lld samples per frame)", (long long)hop);
+    const int64_t T = n_frames * hop;
+    pool_release_all(m);
+    struct Planes { bf16_t* hi = nullptr; bf16_t* lo = nullptr; };
+    auto planes = [&](size_t n, Planes* p) -> int {
+        RT_TRY(pool_arr(m, n, &p->hi));
+        RT_TRY(pool_arr(m, n, &p->lo));
+        return RT_OK;
+    };
+    float* pcm = nullptr;
+    RT_TRY(pool_arr(m, (size_t)T, &pcm));
+    RT_HIP(ctx, hipMemcpyAsync(pcm, h_pcm, (size_t)T * 4, hipMemcpyHostToDevice, ctx->stream));
+    // ---- conv encoder
+    int64_t Tc = T;
+    float* x = nullptr;
+    Planes pa;
+    RT_TRY(pool_arr(m, (size_t)Tc * m->enc_ch[0], &x));
+    RT_TRY(planes((size_t)Tc * m->enc_ch[0], &pa));
+    RT_TRY(launch_enc_conv0(ctx, pcm, Tc, m->enc_ch[0], e.kernel, VEC(m, "enc.conv0_w"), VEC(m, "enc.conv0_b"), x, pa.hi, pa.lo));
+    int ci = 1;
+    auto W = [&](int i) -> const PackedW& { return PW(m, "enc.c" + std::to_string(i)); };
+    auto Bv = [&](int i) { return VEC(m, "enc.c" + std::to_string(i) + "_b"); };
+    for (int st = 0; st < e.n_ratios; ++st) {
+        const int d = m->enc_ch[st], r = e.ratios[st];
+        Planes pb, pn;
+        RT_TRY(planes((size_t)Tc * (d / 2), &pb));
+        {   // residual branch: ELU -> conv k (dilation 1) -> ELU
+            GemmA a; a.ptr = pa.hi; a.ptr_lo = pa.lo; a.split = 1; a.M = Tc; a.Cin = d; a.taps = e.res_kernel; a.tap_stride = 1; a.tap_offset = -(e.res_kernel - 1);
+            a.rows_out = (int)Tc; a.rows_in = (int)Tc;
+            GemmEpi ep; ep.bias = Bv(ci); ep.act = ACT_ELU; ep.out_hi = pb.hi; ep.out_lo = pb.lo; ep.ldc = d / 2;
+            RT_TRY(launch_gemm(ctx, a, W(ci), ep));
+        }
+        {   // -> conv k1, + skip; ELU of the sum is the strided conv's operand
+            GemmA a; a.ptr = pb.hi; a.ptr_lo = pb.lo; a.split = 1; a.M = Tc; a.Cin = d / 2; a.taps = 1;
+            GemmEpi ep; ep.bias = Bv(ci + 1); ep.residual = x; ep.out_f32 = x; ep.out2_hi = pa.hi; ep.out2_lo = pa.lo; ep.act2 = ACT_ELU; ep.ldc = d;
+            RT_TRY(launch_gemm(ctx, a, W(ci + 1), ep));
+        }
+        const int64_t To = Tc / r;
+        float* xn = nullptr;
+        RT_TRY(pool_arr(m, (size_t)To * 2 * d, &xn));
+        RT_TRY(planes((size_t)To * 2 * d, &pn));
+        {   // down-sampling conv k = 2r, stride r
+            GemmA a; a.ptr = pa.hi; a.ptr_lo = pa.lo; a.split = 1; a.M = To; a.Cin = r * d; a.taps = 2; a.tap_stride = 1; a.tap_offset = -1;
+            a.rows_out = (int)To; a.rows_in = (int)To;
+            GemmEpi ep; ep.bias = Bv(ci + 2); ep.out_f32 = xn; ep.out2_hi = pn.hi; ep.out2_lo = pn.lo; ep.act2 = ACT_ELU; ep.ldc = 2 * d;
+            RT_TRY(launch_gemm(ctx, a, W(ci + 2), ep));
+        }
+        x = xn; pa = pn; Tc = To; ci += 3;
+    }
+    const int He = e.tf.hidden;
+    float* feats = nullptr;                        // [Te][He]: conv features at twice the frame rate
+    RT_TRY(pool_arr(m, (size_t)Tc * He, &feats));
+    {
+        GemmA a; a.ptr = pa.hi; a.ptr_lo = pa.lo; a.split = 1; a.M = Tc; a.Cin = m->enc_ch.back(); a.taps = e.last_kernel; a.tap_stride = 1;
+        a.tap_offset = -(e.last_kernel - 1); a.rows_out = (int)Tc; a.rows_in = (int)Tc;
+        GemmEpi ep; ep.bias = Bv(ci); ep.out_f32 = feats; ep.ldc = He;
+        RT_TRY(launch_gemm(ctx, a, W(ci), ep));
+    }
+    const int Te = (int)Tc;                        // = 2 * n_frames
+    // ---- speaker head on the conv features
+    float *stats = nullptr, *sh1 = nullptr, *spk = nullptr;
+    RT_TRY(pool_arr(m, (size_t)2 * He, &stats));
+    RT_TRY(pool_arr(m, (size_t)e.spk_hidden, &sh1));
+    RT_TRY(pool_arr(m, (size_t)c.talker.hidden, &spk));
+    RT_TRY(launch_stats_pool(ctx, feats, Te, He, stats));
+    RT_TRY(launch_gemv_f32(ctx, VEC(m, "enc.spk_fc1"), VEC(m, "enc.spk_fc1_b"), stats, e.spk_hidden, 2 * He, 1, sh1));
+    RT_TRY(launch_gemv_f32(ctx, VEC(m, "enc.spk_fc2"), VEC(m, "enc.spk_fc2_b"), sh1, c.talker.hidden, e.spk_hidden, 0, spk));
+    // ---- transformer (float32-faithful form, sliding window), input = a copy of the features (the stack updates in place)
+    float *h = nullptr, *hn = nullptr;
+    int32_t *d_slot = nullptr, *d_pos = nullptr;
+    RT_TRY(pool_arr(m, (size_t)Te * He, &h));
+    RT_TRY(pool_arr(m, (size_t)(Te + 2) * He, &hn));           // two extra rows in front: the replicate padding of the next conv
+    RT_TRY(pool_arr(m, Te, &d_slot));
+    RT_TRY(pool_arr(m, Te, &d_pos));
+    RT_HIP(ctx, hipMemcpyAsync(h, feats, (size_t)Te * He * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_fill_i32, dim3(8), dim3(256), 0, ctx->stream, d_slot, Te, 0, 0, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3(8), dim3(256), 0, ctx->stream, d_pos, Te, 0, 1, 1);
+    RT_HIP(ctx, hipGetLastError());
+    {
+        StackWs w;
+        RT_TRY(alloc_stack_ws(m, e.tf, Te, &w, true));
+        RT_TRY(stack_forward(m, m->etf, w, h, Te, d_slot, d_pos, 0, nullptr, hn + 2 * He));
+    }
+    // ---- stride-2 conv k = 4 with REPLICATE left padding (2 samples = the first row twice), no bias
+    RT_HIP(ctx, hipMemcpyAsync(hn, hn + 2 * He, (size_t)He * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(hn + He, hn + 2 * He, (size_t)He * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const int Tf = Te / 2;
+    float* emb = nullptr;
+    RT_TRY(pool_arr(m, (size_t)Tf * He, &emb));
+    {
+        GemmA a; a.ptr = hn; a.is_f32 = 1; a.split = 1; a.M = Tf; a.Cin = 2 * He; a.taps = 2; a.tap_stride = 1; a.tap_offset = 0;
+        a.rows_out = Tf; a.rows_in = Tf + 1;
+        GemmEpi ep; ep.out_f32 = emb; ep.ldc = He;
+        RT_TRY(launch_gemm(ctx, a, PW(m, "enc.down"), ep));
+    }
+    // ---- split residual vector quantiser
+    float *sem = nullptr, *aco = nullptr;
+    int32_t* d_codes = nullptr;
+    RT_TRY(pool_arr(m, (size_t)Tf * e.vq_dim, &sem));
+    RT_TRY(pool_arr(m, (size_t)Tf * e.vq_dim, &aco));
+    RT_TRY(pool_arr(m, (size_t)Tf * c.num_quantizers, &d_codes));
+    for (int which = 0; which < 2; ++which) {
+        GemmA a; a.ptr = emb; a.is_f32 = 1; a.split = 1; a.M = Tf; a.Cin = He; a.taps = 1;
+        GemmEpi ep; ep.out_f32 = which ? aco : sem; ep.ldc = e.vq_dim;
+        RT_TRY(launch_gemm(ctx, a, PW(m, which ? "enc.vq_aco" : "enc.vq_sem"), ep));
+    }
+    RT_TRY(launch_rvq(ctx, sem, aco, Tf, e.vq_dim, c.codebook_size, c.num_quantizers, m->d_cbT, d_codes));
+    RT_HIP(ctx, hipMemcpyAsync(h_codes, d_codes, (size_t)Tf * c.num_quantizers * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_speaker_embed) RT_HIP(ctx, hipMemcpyAsync(h_speaker_embed, spk, (size_t)c.talker.hidden * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *h_n_frames = Tf;
+    pool_release_all(m);
+    return RT_OK;
+}
+
+int rt_voice_encode(rt_model* m, const float* h_pcm, int64_t n_samples, int32_t* h_codes, int32_t max_frames, int32_t* h_n_frames,
+                    float* h_speaker_embed) {
+    if (!m || !h_pcm || !h_codes || !h_n_frames || max_frames < 1) return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_voice_encode: null argument");
+    std::lock_guard<std::mutex> g(m->ctx->mu);
+    RT_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    return voice_encode_impl(m, h_pcm, n_samples, h_codes, max_frames, h_n_frames, h_speaker_embed);
+}
+
+int rt_model_set_voice_pcm(rt_model* m, const float* h_pcm, int64_t n_samples, int32_t n_head_rows, const int32_t* h_text_ids,
+                           const int32_t* h_codec_ids, int32_t h_speaker_row, int32_t frame_text_id, int32_t max_ref_frames, int32_t* h_codes,
+                           int32_t* h_n_frames) {
+    if (!m || !h_pcm || n_head_rows < 1 || !h_text_ids || !h_codec_ids || max_ref_frames < 1)
+        return rt_fail(m ? m->ctx : nullptr, RT_ERR_INVALID, "rt_model_set_voice_pcm: null argument");
+    rt_ctx* ctx = m->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const rt_model_config& c = m->cfg;
+    const int G = c.n_groups, Q = c.num_quantizers;
+    if (Q != G) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_model_set_voice_pcm: the codec has %d codebooks but a prompt row takes %d codes", Q, G);
+    if (h_speaker_row >= n_head_rows) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_set_voice_pcm: bad speaker row");
+    std::vector<int32_t> codes((size_t)max_ref_frames * Q);
+    std::vector<float> spk(c.talker.hidden);
+    int32_t nf = 0;
+    RT_TRY(voice_encode_impl(m, h_pcm, n_samples, codes.data(), max_ref_frames, &nf, spk.data()));
+    const int n_rows = n_head_rows + nf;
+    std::vector<int32_t> tid(h_text_ids, h_text_ids + n_head_rows), cid(h_codec_ids, h_codec_ids + (size_t)n_head_rows * G);
+    tid.resize(n_rows, frame_text_id);
+    cid.insert(cid.end(), codes.begin(), codes.begin() + (size_t)nf * Q);
+    if (h_codes) memcpy(h_codes, codes.data(), (size_t)nf * Q * 4);
+    if (h_n_frames) *h_n_frames = nf;
+    return set_voice_impl(m, n_rows, tid.data(), cid.data(), h_speaker_row, h_speaker_row >= 0 ? spk.data() : nullptr);
 }
 
 int32_t rt_voice_prefix_len(rt_model* m) { return m ? m->prefix_len : -1; }

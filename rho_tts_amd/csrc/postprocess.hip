@@ -68,7 +68,23 @@ __device__ __forceinline__ double sumsq_range(const float* p, int64_t lo, int64_
     return acc;
 }
 
-__global__ __launch_bounds__(kThreads) void k_post_item(rt_post_params P, const ItemDesc* __restrict__ items,
+
+// The reference decides "frame is audible" by sqrt(mean square) > threshold in float32 (base_tts.py:369-377).  A frame sitting
+// within an ulp of the threshold (the edge_thresh fixture: a constant signal AT -50 dB) then depends on the last bit of the
+// square root, and the device's sqrt is not the host's.  With a CORRECTLY ROUNDED sqrt the test is monotone in the mean square,
+// so it is evaluated on the mean square against the largest float m with sqrt_rn(m) <= threshold - computed here on the host,
+// exactly - and no square root runs on the device at all.
+static float energy_threshold(float thr) {
+    if (!(thr > 0.f)) return thr == 0.f ? 0.f : (thr < 0.f ? -1.f : thr);   // 0: any energy at all; < 0: every frame; NaN: none
+    auto sqrt_rn = [](float m) { return (float)sqrt((double)m); };
+    float m = thr * thr;
+    while (sqrt_rn(m) <= thr) m = nextafterf(m, INFINITY);
+    while (sqrt_rn(m) > thr) m = nextafterf(m, 0.f);
+    return m;                                                // largest m with sqrt_rn(m) <= thr:  e > thr  <=>  mean square > m
+}
+
+// thr_ms: the frame test "sqrt(mean square) > threshold" as a test on the mean square itself (energy_threshold above)
+__global__ __launch_bounds__(kThreads) void k_post_item(rt_post_params P, float thr_ms, const ItemDesc* __restrict__ items,
                                                         const SegDesc* __restrict__ segs, SegWork* __restrict__ work,
                                                         rt_post_stats* __restrict__ stats) {
     __shared__ double sh_red[kWaves];
@@ -121,8 +137,7 @@ __global__ __launch_bounds__(kThreads) void k_post_item(rt_post_params P, const 
                     const float v = x[i];
                     acc = __fadd_rn(acc, __fmul_rn(v, v));  // same order and rounding as ATen avg_pool1d (CPU)
                 }
-                const float e = __fsqrt_rn(__fdiv_rn(acc, fw));
-                if (e > P.silence_threshold) {
+                if (__fdiv_rn(acc, fw) > thr_ms) {        // == correctly rounded sqrt(mean square) > threshold, without a device sqrt
                     if ((int)f < my_first) my_first = (int)f;
                     if ((int)f > my_last) my_last = (int)f;
                 }
@@ -457,7 +472,7 @@ int post_impl(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32
         gain_off += (p->loud_window > 0 ? out_cap[i] / p->loud_window : 0) + 2;
     }
     RT_HIP(ctx, hipMemcpyAsync(d, h, h_desc, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_post_item, dim3(n_items), dim3(kThreads), 0, ctx->stream, *p, (const ItemDesc*)(d + o_items),
+    hipLaunchKernelGGL(k_post_item, dim3(n_items), dim3(kThreads), 0, ctx->stream, *p, energy_threshold(p->silence_threshold), (const ItemDesc*)(d + o_items),
                        (const SegDesc*)(d + o_segs), (SegWork*)(d + o_work), (rt_post_stats*)(d + o_stats));
     RT_HIP(ctx, hipGetLastError());
     rt_post_stats* hst = (rt_post_stats*)(h + h_desc);

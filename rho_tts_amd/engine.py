@@ -20,7 +20,7 @@ from . import _native
 from ._native_model import NativeModel, RtSampling
 from .config import ModelConfig, resolve
 from .tokenizer import load_tokenizer
-from .voice import VoiceConditioning, conditioning_from_audio, load_audio
+from .voice import VoiceConditioning, load_audio
 from .weights import load_safetensors, synthetic_state
 
 FRAME_SECONDS_PER_WORD = 0.35   # synthetic weights never emit EOS, so length is fixed by policy
@@ -107,11 +107,16 @@ class Engine:
         self.voice = v
         return self.model.set_voice(v.language, v.speaker, v.speaker_embed, v.ref_text_ids, v.ref_codes)
 
-    def set_voice_from_audio(self, audio_or_path, ref_text: str, language: str = "english") -> int:
+    def conditioning_from_audio(self, audio_or_path, ref_text: str, language: str = "english") -> VoiceConditioning:
+        """The conditioning front-end (the reference re-runs it on every call via ref_audio=path, qwen.py:253-258): the clip is
+        encoded ON the GPU - conv encoder, transformer, residual vector quantiser, speaker head (rt_voice_encode) - into the
+        reference codec frames and the speaker embedding of the prompt.  A clip may take at most half of the KV rows."""
         audio = load_audio(audio_or_path, self.cfg.sample_rate) if isinstance(audio_or_path, str) else np.asarray(audio_or_path, np.float32)
-        room = self.model.max_positions // 2
-        v = conditioning_from_audio(self.cfg, audio, self.tokenizer.encode(ref_text), language, max_frames=room)
-        return self.set_voice(v)
+        codes, spk = self.model.encode_voice(audio, max_frames=self.model.max_positions // 2)
+        return VoiceConditioning(language, None, spk, self.tokenizer.encode(ref_text), codes)
+
+    def set_voice_from_audio(self, audio_or_path, ref_text: str, language: str = "english") -> int:
+        return self.set_voice(self.conditioning_from_audio(audio_or_path, ref_text, language))
 
     def set_builtin_voice(self, speaker: str, language: str = "english") -> int:
         return self.set_voice(VoiceConditioning(language, speaker, None, [], None))
