@@ -7,7 +7,8 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 Qwen3-TTS-1.7B-shaped model, bf16 weights, batch 32 per GPU, 30-s reference-audio clone,
 10-word sentences (fixed 44 frames each: synthetic weights never emit EOS — SURVEY.md 8d).
 One step = one pass of the hot path over one batch, everything `_run_pipeline` does after the
-host-side text handling: voice-prefix prefill (conditioning) -> batched autoregressive decode
+host-side text handling: conditioning (reference clip through the audio encoder, voice prefix
+through the talker) -> batched autoregressive decode
 -> codec decoder -> fused post-processing -> waveforms on the host.  Inputs (weights, reference
 conditioning arrays, token ids) are resident before the timed region.  Data is synthetic and
 weights are seeded random of the named architecture (no checkpoints offline).
@@ -104,7 +105,7 @@ def main():
 
     from rho_tts_amd import _native, config
     from rho_tts_amd.engine import Engine
-    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    from rho_tts_amd.voice import synthetic_reference_clip
     from rho_tts_amd.dist import broadcast_voice, gather_waveforms, padding_efficiency, plan_corpus, unshard
 
     cfg = config.PRESETS[args.model]()
@@ -120,7 +121,6 @@ def main():
     ref_words = 75 if args.ref_seconds >= 10 else max(3, int(args.ref_seconds * 2.5))
     clip = synthetic_reference_clip(args.ref_seconds, cfg.sample_rate, 789)
     ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(ref_words))
-    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(ref_text), "english", max_frames=eng.model.max_positions // 2)
     post = _native.make_post_params(sample_rate=cfg.sample_rate, stages=_native.POST_PIPELINE)
     corpus = None
     if args.corpus > 0:
@@ -140,7 +140,9 @@ def main():
 
     def step():
         if dist is None or rank == 0:
-            eng.set_voice(cond)                                   # conditioning: voice-prefix prefill, once per step
+            # conditioning, once per step as the reference does per call (ref_audio=path, qwen.py:253-258): the 30-s clip through
+            # the audio encoder (codes + speaker embedding) and the voice prefix through the talker (its K/V)
+            eng.set_voice_from_audio(clip, ref_text)
         if dist is not None:
             broadcast_voice(eng, dist, src=0, comm_device=comm_dev)
         raw = eng.synthesize(texts, seed=789, item_ids=item_ids, max_frames=my_frames) if texts else []
@@ -285,10 +287,11 @@ def cpu_baseline(cfg, args, eng):
     reference clone, 460-row prefix, prefilled once and shared), 8 decoded frames per item + their codec decode + post-processing;
     the per-frame costs are then extended linearly to the workload's frame count.  Reported beside the GPU number, never as the
     target."""
+    from oracle import encoder as OE
     from oracle import postprocess as OP
     from oracle.model import OracleModel, Voice
     from oracle.sampling import SamplingParams
-    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    from rho_tts_amd.voice import synthetic_reference_clip
     from rho_tts_amd.weights import synthetic_state
 
     cores = min(os.cpu_count() or 1, 32)          # eager PyTorch stops scaling (and small ops get slower) past ~32 threads
@@ -303,32 +306,34 @@ def cpu_baseline(cfg, args, eng):
     texts = sentences(B, args.words, seed=789)
     ref_words = 75 if args.ref_seconds >= 10 else max(3, int(args.ref_seconds * 2.5))
     clip = synthetic_reference_clip(args.ref_seconds, cfg.sample_rate, 789)
-    cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(" ".join(WORDS[i % len(WORDS)] for i in range(ref_words))), "english",
-                                   max_frames=cfg.max_positions // 2)
-    v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
     ids = [eng.tokenizer.encode(t) for t in texts]
-    log("cpu baseline: oracle prefill + decode running ...")
+    log("cpu baseline: oracle conditioning (audio encoder) ...")
     tm = {}
     t0 = time.perf_counter()
     with torch.no_grad():
+        n_clip = (clip.shape[0] // cfg.codec.total_upsample) * cfg.codec.total_upsample
+        ref_codes, spk = OE.encode(om.W, cfg, clip[:n_clip])
+        v = Voice("english", None, spk, eng.tokenizer.encode(" ".join(WORDS[i % len(WORDS)] for i in range(ref_words))), ref_codes)
+        t_enc = time.perf_counter()
+        log(f"cpu baseline: conditioning {t_enc - t0:.1f} s; prefill + decode running ...")
         codes = om.generate(v, ids, [frames] * B, SamplingParams(True, 0.9, 50, 1.0, 1.05), seed=789, share_prefix=True, timing=tm)
         t_dec = time.perf_counter()
         q = cfg.codec.num_quantizers
-        log(f"cpu baseline: prefill {tm['prefill_done'] - t0:.1f} s, {frames} frames in {t_dec - tm['prefill_done']:.1f} s, codec decoder ...")
+        log(f"cpu baseline: prefill {tm['prefill_done'] - t_enc:.1f} s, {frames} frames in {t_dec - tm['prefill_done']:.1f} s, codec decoder ...")
         wav = om.code2wav(torch.stack([c[:, :q].T for c in codes]))
         t_voc = time.perf_counter()
         p = OP.PostParams(sample_rate=cfg.sample_rate)
         for b in range(B):
             OP.finish_item([wav[b]], p)
     t1 = time.perf_counter()
-    prefill, decode, vocode, post = tm["prefill_done"] - t0, t_dec - tm["prefill_done"], t_voc - t_dec, t1 - t_voc
+    cond_s, prefill, decode, vocode, post = t_enc - t0, tm["prefill_done"] - t_enc, t_dec - tm["prefill_done"], t_voc - t_dec, t1 - t_voc
     scale = full_frames / frames
-    t_full = prefill + (decode + vocode + post) * scale
+    t_full = cond_s + prefill + (decode + vocode + post) * scale
     audio_full = B * om.wav_length(full_frames) / cfg.sample_rate
     return {"value": round(audio_full / t_full, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"oracle/model.py (PyTorch eager f32 on bf16-valued weights), {cfg.name}, batch {B}, {args.ref_seconds:g}-s reference clone "
                       f"({om.prefix_embeddings(v).shape[0]}-row prefix prefilled once), {frames} of {full_frames} frames/item decoded + codec decode + "
-                      f"post-processing = {t1 - t0:.1f} s of CPU work (prefill {prefill:.1f}, decode {decode:.1f}, codec {vocode:.1f}, post {post:.1f}); "
+                      f"post-processing = {t1 - t0:.1f} s of CPU work (conditioning {cond_s:.1f}, prefill {prefill:.1f}, decode {decode:.1f}, codec {vocode:.1f}, post {post:.1f}); "
                       f"value = the per-frame costs extended linearly to {full_frames} frames ({t_full:.0f} s)"}
 
 

@@ -1,15 +1,10 @@
-"""Reference-audio -> voice conditioning (speaker embedding + reference codec frames).
+"""Voice-conditioning containers and audio loading, plus a SYNTHETIC code generator for decode-path tests.
 
-STAND-IN.  The real front-end (speaker encoder + codec *encoder* of the
-third-party model, reached by the reference through ``ref_audio=path`` at
-providers/qwen.py:253-258) is SURVEY.md section 8f rank 1 — "next", not part of
-this round's hot path — and no weights exist offline.  What the hot path needs
-from it is only its *output shape*: one embedding of the talker's width and one
-frame of ``n_groups`` codes per 1920 input samples.  This module produces both
-deterministically from the audio (block energies quantised per codebook, an
-embedding hashed from coarse spectral statistics) so that a given clip always
-yields the same conditioning, different clips yield different ones, and the
-prompt has the length a real front-end would give it (30 s -> 375 frames).
+The product path encodes reference audio on the GPU (``Engine.conditioning_from_audio`` -> ``rt_voice_encode``: conv encoder,
+transformer, residual vector quantiser, speaker head; reference call site providers/qwen.py:253-258).  ``conditioning_from_audio``
+below is NOT that: it derives a deterministic prompt of the right SHAPE from block energies (one frame of ``n_groups`` codes per
+1920 samples, a hashed embedding) without running any model, and is kept only so that decode-path parity tests and the CPU
+oracle can be driven by a voice prompt that does not depend on the encoder under test (tests/test_model_shapes_gpu.py).
 """
 from __future__ import annotations
 
