@@ -46,13 +46,28 @@ class SamplingParams:
     repetition_penalty: float = 1.0
 
 
+def scan_f32(p: np.ndarray) -> np.ndarray:
+    """Inclusive prefix sums of up to 64 float32 values in the order the GPU wave computes them: a Kogge-Stone scan, offsets
+    1, 2, 4, ... 32, every addition rounded to float32.  (A defined order, not the left-to-right one: float addition is not
+    associative, and the draw has to be the same token on both sides.)"""
+    x = np.zeros(64, dtype=np.float32)
+    x[: p.shape[0]] = p
+    d = 1
+    while d < 64:
+        y = x.copy()
+        y[d:] = (x[d:] + x[:-d]).astype(np.float32)
+        x = y
+        d *= 2
+    return x[: p.shape[0]]
+
+
 def draw(logits: np.ndarray, sp: SamplingParams, u: np.float32, suppress: np.ndarray | None = None,
          seen: np.ndarray | None = None) -> int:
     """One token from one row of float32 logits.
 
     suppress: bool[V], True = token forbidden.  seen: bool[V], tokens already
     emitted by this sequence (repetition penalty).  All arithmetic float32, in
-    the order written here — the HIP kernel follows the same order.
+    the order written here (running sums: scan_f32) — the HIP kernel follows the same order.
     """
     l = np.array(logits, dtype=np.float32, copy=True)
     if seen is not None and sp.repetition_penalty != 1.0:
@@ -71,23 +86,15 @@ def draw(logits: np.ndarray, sp: SamplingParams, u: np.float32, suppress: np.nda
         return int(np.argmax(l))
     m = l[order[0]]
     p = np.exp((l[order] - m).astype(np.float32)).astype(np.float32)
-    total = np.float32(0)
-    for v in p:
-        total = np.float32(total + v)
+    cum = scan_f32(p)                              # cum[j] = p[0] + ... + p[j] in the scan's evaluation order
+    total = cum[-1]
     keep = p.shape[0]
     if sp.top_p < 1.0:
         lim = np.float32(np.float32(sp.top_p) * total)
-        cum = np.float32(0)
-        for j, v in enumerate(p):
-            cum = np.float32(cum + v)
-            if cum >= lim:
-                keep = j + 1
-                break
-        total = cum
+        reach = np.nonzero(cum >= lim)[0]
+        if reach.size:
+            keep = int(reach[0]) + 1
+            total = cum[keep - 1]
     target = np.float32(u * total)
-    cum = np.float32(0)
-    for j in range(keep):
-        cum = np.float32(cum + p[j])
-        if cum > target:
-            return int(order[j])
-    return int(order[keep - 1])
+    over = np.nonzero(cum[:keep] > target)[0]
+    return int(order[int(over[0])]) if over.size else int(order[keep - 1])

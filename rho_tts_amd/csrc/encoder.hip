@@ -27,31 +27,38 @@ __global__ __launch_bounds__(256) void k_enc_conv0(const float* __restrict__ pcm
     }
 }
 
-// One workgroup per frame walks the quantiser levels: distances of the current vector to all K entries of the level's
-// codebook (transposed [D][K]: at step k the threads read consecutive entries), argmin with the lowest index on ties,
-// residual update.  Level 0 quantises the semantic projection, levels 1.. the acoustic projection residually.
-constexpr int RVQ_T = 256, RVQ_MAXE = 16;        // entries per thread: K <= 4096
-__global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, float* __restrict__ aco, int D, int K, int Q,
+// One workgroup per RVQ_FT frames walks the quantiser levels: distances of the frames' current vectors to all K entries of the
+// level's codebook (transposed [D][K]: at step k the threads read consecutive entries, and every value fetched is used for
+// all RVQ_FT frames - one frame per workgroup re-read the 2-MB codebook per frame and level and was L2-bandwidth-bound),
+// argmin with the lowest index on ties, residual update.  Level 0 quantises the semantic projection, levels 1.. the
+// acoustic projection residually.  1024 threads: K / 1024 entries per thread.
+constexpr int RVQ_T = 1024, RVQ_MAXE = 4, RVQ_FT = 4;        // K <= 4096
+__global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, float* __restrict__ aco, int T, int D, int K, int Q,
                                                const float* const* __restrict__ cbT, int32_t* __restrict__ codes) {
-    extern __shared__ float sh_x[];              // [D]
-    __shared__ float sh_d[RVQ_T];
-    __shared__ int sh_j[RVQ_T];
-    const int t = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float sh_x[];              // [RVQ_FT][D]
+    __shared__ float sh_d[RVQ_FT][RVQ_T / 64];
+    __shared__ int sh_j[RVQ_FT][RVQ_T / 64];
+    __shared__ int sh_win[RVQ_FT];
+    const int t0 = blockIdx.x * RVQ_FT, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ne = (K + RVQ_T - 1) / RVQ_T;
     for (int q = 0; q < Q; ++q) {
-        if (q <= 1) {                             // level 0: semantic vector; level 1: (fresh) acoustic vector; later: residual already in LDS
-            const float* src = (q == 0 ? sem : aco) + (int64_t)t * D;
+        if (q <= 1) {                             // level 0: semantic vectors; level 1: (fresh) acoustic vectors; later: residuals already in LDS
             __syncthreads();
-            for (int k = tid; k < D; k += RVQ_T) sh_x[k] = src[k];
+            for (int i = tid; i < RVQ_FT * D; i += RVQ_T) {
+                const int f = i / D, k = i - f * D;
+                const int t = t0 + f < T ? t0 + f : T - 1;
+                sh_x[i] = (q == 0 ? sem : aco)[(int64_t)t * D + k];
+            }
         }
         __syncthreads();
         const float* cb = cbT[q];
-        float acc[RVQ_MAXE];
+        float acc[RVQ_FT][RVQ_MAXE];
 #pragma unroll
-        for (int i = 0; i < RVQ_MAXE; ++i) acc[i] = 0.f;
-        // KU code dimensions per step: their KU x (K / 256) codebook values are requested together, so the L2 round trip is paid
-        // once per step instead of once per dimension (the per-dimension form spent 11 ms of exposed latency on a 30-s clip);
-        // the sums themselves still run in ascending k, one rounding per operation
+        for (int f = 0; f < RVQ_FT; ++f)
+#pragma unroll
+            for (int i = 0; i < RVQ_MAXE; ++i) acc[f][i] = 0.f;
+        // KU code dimensions per step: their codebook values are requested together, so the L2 round trip is paid once per step;
+        // the sums themselves run in ascending k, one rounding per operation (oracle/encoder.py rvq_level)
         constexpr int KU = 8;
         for (int k0 = 0; k0 < D; k0 += KU) {
             float cv[KU][RVQ_MAXE];
@@ -67,43 +74,62 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (k0 + u < D) {
-                    const float xv = sh_x[k0 + u];
 #pragma unroll
-                    for (int i = 0; i < RVQ_MAXE; ++i) {
-                        if (i < ne) {
-                            const float diff = xv - cv[u][i];
-                            acc[i] = acc[i] + diff * diff;         // (no contraction: see the file header)
+                    for (int f = 0; f < RVQ_FT; ++f) {
+                        const float xv = sh_x[f * D + k0 + u];
+#pragma unroll
+                        for (int i = 0; i < RVQ_MAXE; ++i) {
+                            if (i < ne) {
+                                const float diff = xv - cv[u][i];
+                                acc[f][i] = acc[f][i] + diff * diff;         // (no contraction: see the file header)
+                            }
                         }
                     }
                 }
             }
         }
-        float best = 3.4e38f;
-        int bj = 0x7fffffff;
 #pragma unroll
-        for (int i = 0; i < RVQ_MAXE; ++i) {
-            const int j = tid + i * RVQ_T;
-            if (i < ne && j < K && acc[i] < best) { best = acc[i]; bj = j; }      // ascending j inside a thread: strict <
-        }
-        sh_d[tid] = best;
-        sh_j[tid] = bj;
-        __syncthreads();
-        for (int s = RVQ_T / 2; s > 0; s >>= 1) {
-            if (tid < s) {
-                const float d2 = sh_d[tid + s];
-                const int j2 = sh_j[tid + s];
-                if (d2 < sh_d[tid] || (d2 == sh_d[tid] && j2 < sh_j[tid])) { sh_d[tid] = d2; sh_j[tid] = j2; }
+        for (int f = 0; f < RVQ_FT; ++f) {
+            float best = 3.4e38f;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < RVQ_MAXE; ++i) {
+                const int j = tid + i * RVQ_T;
+                if (i < ne && j < K && acc[f][i] < best) { best = acc[f][i]; bj = j; }      // ascending j inside a thread: strict <
             }
-            __syncthreads();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {         // (distance, index) minimum: lowest index on equal distances
+                const float d2 = __shfl_xor(best, o, 64);
+                const int j2 = __shfl_xor(bj, o, 64);
+                if (d2 < best || (d2 == best && j2 < bj)) { best = d2; bj = j2; }
+            }
+            if (lane == 0) { sh_d[f][w] = best; sh_j[f][w] = bj; }
         }
-        const int win = sh_j[0];
-        if (tid == 0) codes[(int64_t)t * Q + q] = win;
-        if (q >= 1) {                             // residual for the next acoustic level
-            for (int k = tid; k < D; k += RVQ_T) sh_x[k] = sh_x[k] - cb[(int64_t)k * K + win];
+        __syncthreads();
+        if (tid < RVQ_FT) {
+            float best = sh_d[tid][0];
+            int bj = sh_j[tid][0];
+            for (int ww = 1; ww < RVQ_T / 64; ++ww) {
+                const float d2 = sh_d[tid][ww];
+                const int j2 = sh_j[tid][ww];
+                if (d2 < best || (d2 == best && j2 < bj)) { best = d2; bj = j2; }
+            }
+            sh_win[tid] = bj;
+            if (t0 + tid < T) codes[(int64_t)(t0 + tid) * Q + q] = bj;
+        }
+        __syncthreads();
+        if (q >= 1) {                             // residuals for the next acoustic level
+            for (int i = tid; i < RVQ_FT * D; i += RVQ_T) {
+                const int f = i / D, k = i - f * D;
+                sh_x[i] = sh_x[i] - cb[(int64_t)k * K + sh_win[f]];
+            }
         }
         __syncthreads();
     }
-    for (int k = tid; k < D; k += RVQ_T) aco[(int64_t)t * D + k] = sh_x[k];
+    for (int i = tid; i < RVQ_FT * D; i += RVQ_T) {
+        const int f = i / D, k = i - f * D;
+        if (t0 + f < T) aco[(int64_t)(t0 + f) * D + k] = sh_x[i];
+    }
 }
 
 // one workgroup per 64 channels; threads = 4 time lanes x 64 channels, two passes (mean, then variance about it)
@@ -155,7 +181,7 @@ int launch_enc_conv0(rt_ctx* ctx, const float* pcm, int64_t T, int C, int k, con
 int launch_rvq(rt_ctx* ctx, const float* sem, float* aco, int T, int D, int K, int Q, const float* const* d_cbT, int32_t* codes) {
     if (T <= 0) return RT_OK;
     if (K > RVQ_T * RVQ_MAXE || D > 4096 || Q < 1) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rvq: codebook of %d entries x %d (max %d x 4096)", K, D, RVQ_T * RVQ_MAXE);
-    hipLaunchKernelGGL(k_rvq, dim3(T), dim3(RVQ_T), (size_t)D * 4, ctx->stream, sem, aco, D, K, Q, d_cbT, codes);
+    hipLaunchKernelGGL(k_rvq, dim3((T + RVQ_FT - 1) / RVQ_FT), dim3(RVQ_T), (size_t)RVQ_FT * D * 4, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

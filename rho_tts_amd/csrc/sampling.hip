@@ -170,20 +170,23 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
                 if (n > 0) {
                     const float mx = __shfl(c.v, 0, 64);
                     const float p = tid < n ? expf(__fsub_rn(c.v, mx)) : 0.f;
-                    float total = 0.f;
-                    for (int j = 0; j < n; ++j) total = __fadd_rn(total, __shfl(p, j, 64));
+                    // running sums by the Kogge-Stone scan oracle/sampling.py defines (scan_f32), as in k_sample_w
+                    float cum = p;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const float o = __shfl_up(cum, d, 64);
+                        if (tid >= d) cum = __fadd_rn(cum, o);
+                    }
+                    float total = __shfl(cum, n - 1, 64);
                     int keep = n;
                     if (A.top_p < 1.0f) {
                         const float lim = __fmul_rn(A.top_p, total);
-                        float cum = 0.f;
-                        for (int j = 0; j < n; ++j) { cum = __fadd_rn(cum, __shfl(p, j, 64)); if (cum >= lim) { keep = j + 1; break; } }
-                        total = cum;
+                        const unsigned long long reach = __ballot(tid < n && cum >= lim);
+                        if (reach) { keep = __builtin_ctzll(reach) + 1; total = __shfl(cum, keep - 1, 64); }
                     }
                     const float u = rt_uniform(A.seed, (unsigned)A.item_ids[row], (unsigned)A.frame, (unsigned)A.group);
                     const float target = __fmul_rn(u, total);
-                    float cum = 0.f;
-                    int pick_lane = keep - 1;
-                    for (int j = 0; j < keep; ++j) { cum = __fadd_rn(cum, __shfl(p, j, 64)); if (cum > target) { pick_lane = j; break; } }
+                    const unsigned long long over = __ballot(tid < keep && cum > target);
+                    const int pick_lane = over ? __builtin_ctzll(over) : keep - 1;
                     const int pick = __shfl(c.idx, pick_lane, 64);
                     if (tid == 0) sh_i[0] = pick;
                 } else if (tid == 0) {
@@ -384,33 +387,38 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
                 b2 += __popcll(bs);
             }
             if (A.stamps && row == 0 && tid == 0) A.stamps[4] = wall_clock64();
-            // ---- order by (value desc, index asc): rank = number of candidates ahead of mine (keys are unique), one
-            // scalar broadcast per candidate, then a scatter through LDS puts candidate r on lane r
+            // ---- order by (value desc, index asc): one-wave bitonic network over the 64 lanes (21 compare-exchange stages of two
+            // shuffles each; the scalar-broadcast rank sort it replaces cost 1.7 us at k = 50).  Unused lanes hold (-inf, INT_MAX)
+            // and sink to the end.
             Cand c = fin[lane];
-            const unsigned my_hi = okey(c.v), my_lo = 0xFFFFFFFFu - (unsigned)c.idx;     // larger 64-bit key = earlier
-            const unsigned long long my64 = ((unsigned long long)my_hi << 32) | my_lo;
-            int rank = 0;
-#pragma unroll 4
-            for (int j = 0; j < kf; ++j) {
-                const unsigned long long o64 = ((unsigned long long)(unsigned)lane_i32((int)my_hi, j) << 32) | (unsigned)lane_i32((int)my_lo, j);
-                rank += o64 > my64 ? 1 : 0;
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    Cand o;
+                    o.v = __shfl_xor(c.v, j, 64);
+                    o.idx = __shfl_xor(c.idx, j, 64);
+                    const bool keep_first = ((lane & kk) == 0) == ((lane & j) == 0);      // this lane keeps the earlier of the pair
+                    if (keep_first ? before(o, c) : before(c, o)) c = o;
+                }
             }
-            if (lane < kf) sorted[rank] = c;
-            c = lane < kf ? sorted[lane] : Cand{-INFINITY, 0x7fffffff};
             if (A.stamps && row == 0 && tid == 0) A.stamps[5] = wall_clock64();
             const unsigned long long fin_mask = __ballot(lane < kf && c.v > -INFINITY);
             const int n = __popcll(fin_mask);                                  // finite candidates are a prefix after the sort
             if (n > 0) {
                 const float mx = lane_f32(c.v, 0);
                 const float p = lane < n ? expf(__fsub_rn(c.v, mx)) : 0.f;
-                // ONE sequential pass builds the ordered running sums (cum_j lands on lane j): the total, the top-p cut and
-                // the inverse-CDF pick are then ballots over them - the same additions in the same order as the oracle's
-                // three loops, each done once
-                float cum = 0.f, mycum = 0.f;
-                for (int j = 0; j < n; ++j) {
-                    cum = __fadd_rn(cum, lane_f32(p, j));
-                    if (lane == j) mycum = cum;
+                // running sums in sorted order by a Kogge-Stone scan (6 shuffle + add steps, each add rounded to float32): cum_j
+                // lands on lane j.  oracle/sampling.py defines the SAME evaluation order (scan_f32), so totals, the top-p cut and
+                // the inverse-CDF pick are bit-identical on both sides; the 50-step scalar walk this replaces cost 1.8 us.
+                float cum = p;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float o = __shfl_up(cum, d, 64);
+                    if (lane >= d) cum = __fadd_rn(cum, o);
                 }
+                const float mycum = cum;
+                cum = lane_f32(mycum, n - 1);
                 float tot = cum;
                 int keep = n;
                 if (A.top_p < 1.0f) {

@@ -6,7 +6,7 @@ import torch
 import bench
 from rho_tts_amd import _native, config
 from rho_tts_amd.engine import Engine
-from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+from rho_tts_amd.voice import synthetic_reference_clip
 
 cfg = config.PRESETS["1.7b"]()
 eng = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32, synthetic=True)
@@ -15,7 +15,6 @@ for code in sys.argv[1:]:
 texts = bench.sentences(32, 10, seed=789)
 clip = synthetic_reference_clip(30.0, cfg.sample_rate, 789)
 ref_text = " ".join(bench.WORDS[i % len(bench.WORDS)] for i in range(75))
-cond = conditioning_from_audio(cfg, clip, eng.tokenizer.encode(ref_text), "english", max_frames=eng.model.max_positions // 2)
 post = _native.make_post_params(sample_rate=cfg.sample_rate, stages=_native.POST_PIPELINE)
 
 
@@ -31,6 +30,7 @@ def timed(label, fn, acc):
 
 for rep in range(4):
     acc = {}
+    cond = timed("encode", lambda: eng.conditioning_from_audio(clip, ref_text), acc)
     timed("set_voice", lambda: eng.set_voice(cond), acc)
     codes = timed("generate_codes", lambda: eng.generate_codes(texts, 789, list(range(32))), acc)
     raw = timed("vocode", lambda: eng.vocode(codes), acc)
