@@ -317,7 +317,8 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   700/701 32-row / 64-row decode GEMM launches | 800/801 separate / fused sampler + next-input embedding |
  *   90n prefill split-K target of n workgroups per CU | 1000/1001 XCD-aware tile order of the tiled GEMM off/on |
  *   1300/1301 stream sync after every decode frame part off/on (bounds the dispatches in flight under rocprofv3 --pmc) |
- *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame)
+ *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame) |
+ *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);

@@ -291,6 +291,9 @@ int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int 
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
                            const int32_t* frame_ptr, int out_tiled) {
+    if (attention_mfma_ok(M, heads, kv_heads, head_dim, window, kv))
+        return launch_attention_prefix_mfma(ctx, qkv, M, heads, kv_heads, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, kv, layer,
+                                            out, frame_ptr, out_tiled);
     FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

@@ -200,9 +200,21 @@ int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t
     KvCache kv;
     kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
     kv.prefix_slot = prefix_slot; kv.prefix_len = prefix_slot >= 0 ? prefix_len : 0;
+    bf16_t* vt = nullptr;
+    if (prefix_slot >= 0 && prefix_len > 0 && head_dim == 128) {      // the matrix-core path reads the prefix through fragment-tiled copies
+        kv.vt_stride = (prefix_len + 31) / 32 * 4096;
+        kv.prefix_slot_alloc = prefix_slot;
+        RT_HIP(ctx, hipMalloc((void**)&vt, (size_t)2 * kv_heads * kv.vt_stride * 2));
+        kv.kt_prefix = vt;
+        kv.vt_prefix = vt + (size_t)kv_heads * kv.vt_stride;
+        const int rt = launch_transpose_prefix_v(ctx, kv, prefix_len);
+        if (rt) { (void)hipFree(vt); return rt; }
+    }
     const int rc = launch_attention_fused(ctx, d_qkv, M, heads, kv_heads, head_dim, d_q_norm_w, d_k_norm_w, eps, d_cos, d_sin, d_row_slot, d_row_pos,
                                           pos_add, 0, kv, 0, (bf16_t*)d_out_bf16, nullptr, 0);
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (vt) (void)hipFree(vt);
+    RT_HIP(ctx, se);
     return rc;
 }
 
@@ -227,6 +239,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 1500) { g_attn_mfma = skinny_variant - 1500; return RT_OK; }            // 1500/1501: MFMA shared-prefix decode attention off/on
     if (skinny_variant >= 1400) { g_eos_check_every = std::max(1, skinny_variant - 1400); return RT_OK; }   // 14nn: look at the end-of-sequence flags every nn frames
     if (skinny_variant >= 1300) { g_sync_parts = skinny_variant - 1300; return RT_OK; }             // 1300/1301: stream sync after every frame part off/on
     if (skinny_variant >= 1200) { g_conv_win = skinny_variant - 1200; return RT_OK; }               // 1200/1201: conv input window in LDS off/on

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void k_enc_conv0(const float* __restrict__ pcm
 // all RVQ_FT frames - one frame per workgroup re-read the 2-MB codebook per frame and level and was L2-bandwidth-bound),
 // argmin with the lowest index on ties, residual update.  Level 0 quantises the semantic projection, levels 1.. the
 // acoustic projection residually.  1024 threads: K / 1024 entries per thread.
-constexpr int RVQ_T = 1024, RVQ_MAXE = 4, RVQ_FT = 4;        // K <= 4096
+constexpr int RVQ_T = 1024, RVQ_MAXE = 4, RVQ_FT = 2;        // K <= 4096
+template <int NE>                                            // codebook entries per thread = ceil(K / 1024)
 __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, float* __restrict__ aco, int T, int D, int K, int Q,
                                                const float* const* __restrict__ cbT, int32_t* __restrict__ codes) {
     extern __shared__ float sh_x[];              // [RVQ_FT][D]
@@ -40,7 +41,6 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
     __shared__ int sh_j[RVQ_FT][RVQ_T / 64];
     __shared__ int sh_win[RVQ_FT];
     const int t0 = blockIdx.x * RVQ_FT, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ne = (K + RVQ_T - 1) / RVQ_T;
     for (int q = 0; q < Q; ++q) {
         if (q <= 1) {                             // level 0: semantic vectors; level 1: (fresh) acoustic vectors; later: residuals already in LDS
             __syncthreads();
@@ -52,23 +52,23 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
         }
         __syncthreads();
         const float* cb = cbT[q];
-        float acc[RVQ_FT][RVQ_MAXE];
+        float acc[RVQ_FT][NE];
 #pragma unroll
         for (int f = 0; f < RVQ_FT; ++f)
 #pragma unroll
-            for (int i = 0; i < RVQ_MAXE; ++i) acc[f][i] = 0.f;
+            for (int i = 0; i < NE; ++i) acc[f][i] = 0.f;
         // KU code dimensions per step: their codebook values are requested together, so the L2 round trip is paid once per step;
         // the sums themselves run in ascending k, one rounding per operation (oracle/encoder.py rvq_level)
         constexpr int KU = 8;
         for (int k0 = 0; k0 < D; k0 += KU) {
-            float cv[KU][RVQ_MAXE];
+            float cv[KU][NE];
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const float* row = cb + (int64_t)(k0 + u < D ? k0 + u : D - 1) * K;
 #pragma unroll
-                for (int i = 0; i < RVQ_MAXE; ++i) {
+                for (int i = 0; i < NE; ++i) {
                     const int j = tid + i * RVQ_T;
-                    cv[u][i] = (i < ne && j < K) ? row[j] : 0.f;
+                    cv[u][i] = row[j < K ? j : K - 1];          // (clamped, unconditional: the entry is ignored in the argmin)
                 }
             }
 #pragma unroll
@@ -78,11 +78,9 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
                     for (int f = 0; f < RVQ_FT; ++f) {
                         const float xv = sh_x[f * D + k0 + u];
 #pragma unroll
-                        for (int i = 0; i < RVQ_MAXE; ++i) {
-                            if (i < ne) {
-                                const float diff = xv - cv[u][i];
-                                acc[f][i] = acc[f][i] + diff * diff;         // (no contraction: see the file header)
-                            }
+                        for (int i = 0; i < NE; ++i) {
+                            const float diff = xv - cv[u][i];
+                            acc[f][i] = acc[f][i] + diff * diff;             // (no contraction: see the file header)
                         }
                     }
                 }
@@ -93,9 +91,9 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
             float best = 3.4e38f;
             int bj = 0x7fffffff;
 #pragma unroll
-            for (int i = 0; i < RVQ_MAXE; ++i) {
+            for (int i = 0; i < NE; ++i) {
                 const int j = tid + i * RVQ_T;
-                if (i < ne && j < K && acc[f][i] < best) { best = acc[f][i]; bj = j; }      // ascending j inside a thread: strict <
+                if (j < K && acc[f][i] < best) { best = acc[f][i]; bj = j; }      // ascending j inside a thread: strict <
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {         // (distance, index) minimum: lowest index on equal distances
@@ -181,7 +179,14 @@ int launch_enc_conv0(rt_ctx* ctx, const float* pcm, int64_t T, int C, int k, con
 int launch_rvq(rt_ctx* ctx, const float* sem, float* aco, int T, int D, int K, int Q, const float* const* d_cbT, int32_t* codes) {
     if (T <= 0) return RT_OK;
     if (K > RVQ_T * RVQ_MAXE || D > 4096 || Q < 1) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rvq: codebook of %d entries x %d (max %d x 4096)", K, D, RVQ_T * RVQ_MAXE);
-    hipLaunchKernelGGL(k_rvq, dim3((T + RVQ_FT - 1) / RVQ_FT), dim3(RVQ_T), (size_t)RVQ_FT * D * 4, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes);
+    const dim3 grid((T + RVQ_FT - 1) / RVQ_FT);
+    const size_t lds = (size_t)RVQ_FT * D * 4;
+    switch ((K + RVQ_T - 1) / RVQ_T) {
+        case 1: hipLaunchKernelGGL(k_rvq<1>, grid, dim3(RVQ_T), lds, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes); break;
+        case 2: hipLaunchKernelGGL(k_rvq<2>, grid, dim3(RVQ_T), lds, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes); break;
+        case 3: hipLaunchKernelGGL(k_rvq<3>, grid, dim3(RVQ_T), lds, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes); break;
+        default: hipLaunchKernelGGL(k_rvq<4>, grid, dim3(RVQ_T), lds, ctx->stream, sem, aco, T, D, K, Q, d_cbT, codes); break;
+    }
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -700,6 +700,8 @@ int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its 
 int g_conv_win = 1;             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
+int g_attn_mfma = 0;             // 1: the talker's decode attention runs its shared-prefix part on the matrix cores (attention_mfma.hip);
+                                // measured 16.6 us per launch against 13.3 us for the vector-unit kernel at batch 32 / 460 prefix rows, so off
 int g_eos_check_every = 8;      // frames between two host looks at the device-side end-of-sequence flags (1 = every frame)
 int g_sync_parts = 0;           // 1: rt_generate waits for the stream after every frame part (bounds the dispatches in flight; profiling aid)
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)

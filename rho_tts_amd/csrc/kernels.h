@@ -161,6 +161,12 @@ struct KvCache {
     // Shared voice prefix: cache rows [0, prefix_len) of EVERY sequence are read from slot `prefix_slot` (one copy in HBM,
     // served from L2 / Infinity Cache to all the workgroups that re-read it) instead of a per-sequence copy.  -1 = off.
     int prefix_slot = -1, prefix_len = 0;
+    // Fragment-tiled copies of the prefix slot's K and V, [layers][kv_heads][vt_stride] (32-key blocks of 8 MFMA operand tiles,
+    // zero padded): what the matrix-core decode attention (attention_mfma.hip) loads; rebuilt whenever the prefix changes.
+    bf16_t* kt_prefix = nullptr;
+    bf16_t* vt_prefix = nullptr;
+    int vt_stride = 0;              // elements per (layer, kv head) = ceil(max_pos / 32) * 4096
+    int prefix_slot_alloc = -1;     // the slot that holds the prefix (fixed per model; prefix_slot above is switched on / off around its prefill)
     size_t layer_stride() const { return (size_t)slots * kv_heads * max_pos * head_dim; }
 };
 // qkv slabs [S][M][(heads+2*kv_heads)*d] -> q (f32 [M][heads][d], normed + roped), k/v appended to the cache
@@ -180,6 +186,15 @@ int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int 
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
                            const int32_t* frame_ptr = nullptr, int out_tiled = 0);
+
+// decode attention with the shared prefix on the matrix cores (attention_mfma.hip): same contract as launch_attention_fused for
+// head_dim 128, 2 query heads per kv head, no window, a shared prefix of >= 64 rows with its transposed V copy in place
+extern int g_attn_mfma;
+bool attention_mfma_ok(int M, int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
+int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, const float* q_norm_w, const float* k_norm_w, float eps,
+                                 const float* rope_cos, const float* rope_sin, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
+                                 const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled);
+int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len);
 
 // ------------------------------------------------------------------------------ embedding kernels
 // out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.

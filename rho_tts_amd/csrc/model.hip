@@ -600,6 +600,8 @@ int rt_model_destroy(rt_model* m) {
         if (S->kv.v) (void)hipFree(S->kv.v);
         if (S->kv.k_lo) (void)hipFree(S->kv.k_lo);
         if (S->kv.v_lo) (void)hipFree(S->kv.v_lo);
+        if (S->kv.vt_prefix) (void)hipFree(S->kv.vt_prefix);
+        if (S->kv.kt_prefix) (void)hipFree(S->kv.kt_prefix);
         if (S->cos) (void)hipFree(S->cos);
         if (S->sin) (void)hipFree(S->sin);
     }
@@ -692,6 +694,13 @@ int rt_model_finalize(rt_model* m, const float* h_rope_cos[3], const float* h_ro
         if (!s.set) return rt_fail(ctx, RT_ERR_INVALID, "rt_model_finalize: tensor '%s' was never set", s.name.c_str());
     const rt_model_config& c = m->cfg;
     RT_TRY(bind_stack(m, m->talker, "talker", c.talker, c.max_batch + 1, c.max_positions, 0));
+    if (c.talker.head_dim == 128) {   // transposed copy of the voice prefix's V for the matrix-core decode attention (attention_mfma.hip)
+        KvCache& kv = m->talker.kv;
+        kv.vt_stride = (c.max_positions + 31) / 32 * 4096;
+        kv.prefix_slot_alloc = m->prefix_slot();
+        RT_HIP(ctx, hipMalloc((void**)&kv.kt_prefix, (size_t)kv.layers * kv.kv_heads * kv.vt_stride * sizeof(bf16_t)));
+        RT_HIP(ctx, hipMalloc((void**)&kv.vt_prefix, (size_t)kv.layers * kv.kv_heads * kv.vt_stride * sizeof(bf16_t)));
+    }
     RT_TRY(bind_stack(m, m->pred, "pred", c.predictor, c.max_batch, c.n_groups + 1, 0));
     RT_TRY(bind_stack(m, m->ctf, "ctf", c.codec_tf, c.max_batch, c.max_codec_frames, c.codec_sliding_window, true));
     StackW* stacks[3] = {&m->talker, &m->pred, &m->ctf};
@@ -832,6 +841,7 @@ static int set_voice_impl(rt_model* m, int32_t n_rows, const int32_t* h_text_ids
     bf16_t* hn = nullptr;
     RT_TRY(pool_arr(m, (size_t)n_rows * H, &hn));
     RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr));
+    if (c.talker.head_dim == 128) RT_TRY(launch_transpose_prefix_v(ctx, m->talker.kv, n_rows));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->prefix_len = n_rows;
     pool_release_all(m);
@@ -1028,6 +1038,7 @@ static int voice_blob(rt_model* m, void* d_blob, int64_t bytes, int to_blob, int
     hipLaunchKernelGGL(k_kv_blob, dim3(d.layers * d.kv_heads, 2), dim3(256), 0, ctx->stream, kv.k, kv.v, (int64_t)kv.layer_stride(), d.layers,
                        d.kv_heads, kv.max_pos, d.head_dim, m->prefix_slot(), prefix_len, (bf16_t*)d_blob, to_blob);
     RT_HIP(ctx, hipGetLastError());
+    if (!to_blob && d.head_dim == 128) RT_TRY(launch_transpose_prefix_v(ctx, kv, prefix_len));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!to_blob) m->prefix_len = prefix_len;
     return RT_OK;
