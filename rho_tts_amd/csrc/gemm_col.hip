@@ -285,6 +285,7 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 // gate/up GEMM (N = 2 * inter): a workgroup owns a gate tile and its up tile, N/32 workgroups.  Halving the tiles to even out
 // the 1.5 rounds of the 1.7B talker (384 workgroups on 256 CUs) was measured slower (21.5 vs 17.4 us: every workgroup
 // re-reads the whole A operand), so the split is only taken when forced through rt_debug_tune(502/504).
+int g_col_split4 = 0;            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
 int col_split_silu(int N, int n_cu) {
     (void)N; (void)n_cu;
     return (g_col_split == 2 || g_col_split == 4) ? g_col_split : 1;
@@ -294,6 +295,7 @@ int col_split_silu(int N, int n_cu) {
 int col_split_for(int N, int n_cu) {
     if (g_col_split == 1 || g_col_split == 2 || g_col_split == 4) return g_col_split;
     const int tiles = (N + 15) / 16;
+    if (g_col_split4 && tiles * 4 <= n_cu) return 4;      // N <= 1024 on 256 CUs: a quarter tile per workgroup puts one on every CU
     if (tiles * 2 <= n_cu) return 2;
     return 1;
 }
