@@ -19,10 +19,14 @@ finished waveforms are gathered to rank 0, both inside the timed step.
 
 `--corpus N` switches to BASELINE.json configs[3] (C4): ONE corpus of N ragged texts (seed 789,
 U{6..24} words) for the whole job — strong scaling.  The corpus is dealt over the ranks by
-estimated frames (dist.shard_items), every rank buckets its share into batches of `--batch`
-by length (dist.bucket_batches), decodes, post-processes, and the waveforms are gathered to rank 0
-and put back in corpus order (dist.unshard).  The line then also reports the padding efficiency
-sum(frames) / sum(batch max x batch size) of the cut.
+estimated frames (dist.plan_corpus); every rank decodes its share on its `--batch` rows with
+continuous batching (ONE rt_generate call: texts queued longest first, a finished row is handed to
+the next queued text), vocodes in batches sorted by the lengths produced, post-processes, and the
+waveforms are gathered to rank 0 and put back in corpus order (dist.unshard).  The line also
+reports the measured row occupancy (`extra.padding_efficiency` = frames kept / (frames launched x
+rows)).  `--static-batches`: length-bucketed static batches instead (dist.bucket_batches).
+`--length-error e`: every text ends at estimate x (1 + U(-e, e)) frames while the schedule is
+planned on the estimates - what a real checkpoint's end-of-sequence does to a planner.
 
 `value` counts DELIVERED audio: the samples of the post-processed waveforms the caller receives
 (after silence trim), not the vocoder's raw output.
@@ -81,6 +85,9 @@ def main():
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--corpus", type=int, default=0, help="C4: one corpus of this many ragged texts for the whole job (strong scaling)")
+    ap.add_argument("--length-error", type=float, default=0.0, help="corpus mode: every text ends at estimate x (1 + U(-e, e)) frames - the schedule is "
+                    "planned on the estimates, as with a real checkpoint whose end-of-sequence the host cannot know (synthetic weights never emit it)")
+    ap.add_argument("--static-batches", action="store_true", help="corpus mode: length-bucketed static batches instead of continuous batching")
     ap.add_argument("--eos-live", action="store_true", help="decode with end-of-sequence live (as a real checkpoint does) instead of fixed lengths")
     ap.add_argument("--tune", default="", help="comma-separated rt_debug_tune codes (100/101 legacy/column decode, 200/201 eager/graph)")
     args = ap.parse_args()
@@ -131,12 +138,21 @@ def main():
         shards, plans = plan_corpus(c_frames, world, B)
         texts = [corpus[i] for i in shards[rank]]
         item_ids = list(shards[rank])
-        my_frames = [c_frames[i] for i in shards[rank]]
+        my_plan = [c_frames[i] for i in shards[rank]]
+        if args.length_error > 0:
+            import random
+            rnd = random.Random(4242)
+            actual = [max(2, int(round(f * (1.0 + args.length_error * (2.0 * rnd.random() - 1.0))))) for f in c_frames]
+        else:
+            actual = c_frames
+        my_frames = [actual[i] for i in shards[rank]]
         pad_eff = padding_efficiency(c_frames, [b for pl in plans for b in pl])
     else:
         texts = sentences(B, args.words, seed=789 + rank)
         item_ids = list(range(rank * B, (rank + 1) * B))
-        my_frames = None
+        my_frames = my_plan = None
+
+    sched = {}                                                # kept / launched row-frames of the decode schedule (this rank, all steps)
 
     def step():
         if dist is None or rank == 0:
@@ -145,7 +161,8 @@ def main():
             eng.set_voice_from_audio(clip, ref_text)
         if dist is not None:
             broadcast_voice(eng, dist, src=0, comm_device=comm_dev)
-        raw = eng.synthesize(texts, seed=789, item_ids=item_ids, max_frames=my_frames) if texts else []
+        raw = eng.synthesize(texts, seed=789, item_ids=item_ids, max_frames=my_frames, plan_frames=my_plan, stats=sched,
+                             continuous=False if args.static_batches else None) if texts else []
         outs, stats = eng.post_process([[w] for w in raw], post) if raw else ([], [])
         audio_s = sum(o.numel() for o in outs) / cfg.sample_rate   # delivered (post-processed) samples
         if dist is not None:
@@ -168,6 +185,7 @@ def main():
         eng.ctx.synchronize()
 
     sync()
+    sched.clear()
     t0 = time.perf_counter()
     audio_local = 0.0
     for _ in range(args.steps):
@@ -227,8 +245,14 @@ def main():
         kv = B * ctx_len * t_.layers * 2 * t_.kv_heads * t_.head_dim * 2
         extra = {"bytes_per_frame": int(w_talker + w_pred + kv), "frames_per_item": frames, "prefix_rows": eng.model.prefix_len()}
     if corpus is not None:
-        extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(c_frames)), "padding_efficiency": round(pad_eff, 4),
-                      "batches_per_rank": [len(pl) for pl in plans]})
+        extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(actual)), "length_error": args.length_error,
+                      # rows kept busy by the decode schedule of rank 0, measured (kept frames / (frames launched x rows));
+                      # `planned` is what static length-bucketed batches of the same shards would give
+                      "padding_efficiency": round(sched.get("frames", 0) / max(1, sched.get("padded_frames", 1)), 4),
+                      "padding_efficiency_static_plan": round(pad_eff, 4),
+                      "schedule": "static length-bucketed batches" if (args.static_batches or B > 32) else "continuous batching (finished rows handed to queued texts)",
+                      "row_hand_overs_per_step": sched.get("hand_overs", 0) // max(1, args.steps),
+                      "batches_per_rank_static_plan": [len(pl) for pl in plans]})
 
     # time to first audio of the streaming entry (BaseTTS.stream yields per segment, base_tts.py:1132-1190): one text alone,
     # call -> decoded, vocoded, post-processed, 16-bit PCM of the first segment on the host
@@ -266,7 +290,7 @@ def main():
             "config": {"workload": (f"{cfg.name} bf16, batch {B}/GPU, {args.ref_seconds:g}-s reference clone, "
                                     + (f"{args.words}-word sentences ({eng.frames_for(texts[0], 0)} frames each)" if corpus is None else
                                        f"ONE corpus of {len(corpus)} texts of 6-24 words ({min(c_frames)}-{max(c_frames)} frames) sharded by length over the ranks, "
-                                       f"length-bucketed batches")
+                                       + ("length-bucketed static batches" if (args.static_batches or B > 32) else "continuous batching on the rank's decode rows"))
                                     + f", sampling={'greedy' if args.greedy else 'top-k 50 T 0.9'}, seeded synthetic weights; "
                                     "value counts delivered (post-processed) audio"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},

@@ -36,7 +36,7 @@ extern "C" {
 
 #define RT_API __attribute__((visibility("default")))
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -237,6 +237,11 @@ RT_API int64_t rt_voice_blob_bytes(rt_model* m);
 RT_API int rt_voice_export(rt_model* m, void* d_blob, int64_t bytes);
 RT_API int rt_voice_import(rt_model* m, int32_t prefix_len, const void* d_blob, int64_t bytes);
 
+/* n_items may exceed the model's max_batch: the first max_batch items start on the decode rows, the others wait in a queue
+ * (in array order - put the longest first) and take over a row as soon as the host has seen its item finish: the new item's
+ * prompt suffix is prefilled into the row's KV slot between two frames (continuous batching).  An item's codes depend only
+ * on (h_item_ids[i], seed), not on the row or the moment it ran.  Teacher forcing and the logit traces need
+ * n_items <= max_batch. */
 typedef struct rt_generate_args {
     int32_t n_items;
     const int32_t* h_text_ids;      /* concatenated target-text token ids                          */
@@ -258,6 +263,9 @@ typedef struct rt_generate_args {
 } rt_generate_args;
 
 RT_API int rt_generate(rt_model* m, const rt_generate_args* args);
+/* Figures of the last rt_generate: decode frames launched, rows, frames kept over all items (row occupancy =
+ * frames_kept / (frames_run * rows)) and the number of row hand-overs to queued items.  Any pointer may be NULL. */
+RT_API int rt_generate_stats(rt_model* m, int64_t* frames_run, int64_t* rows, int64_t* frames_kept, int64_t* hand_overs);
 
 /* Codec decoder: h_codes [n_items][t_max][num_quantizers] (right-padded), h_n_frames [n_items];
  * d_wav [n_items][wav_stride] float32 in HBM, h_wav_len out.  rt_wav_length(frames) = samples produced. */
@@ -318,7 +326,8 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   90n prefill split-K target of n workgroups per CU | 1000/1001 XCD-aware tile order of the tiled GEMM off/on |
  *   1300/1301 stream sync after every decode frame part off/on (bounds the dispatches in flight under rocprofv3 --pmc) |
  *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame) |
- *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores
+ *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores | 1600/1601 quarter-tile split off/on |
+ *   17nn queued items (rt_generate with n_items > max_batch) take over finished rows every nn frames (default 4)
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);

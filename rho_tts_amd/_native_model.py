@@ -68,6 +68,7 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_voice_export.argtypes = [vp, vp, i64]
     lib.rt_voice_import.argtypes = [vp, i32, vp, i64]
     lib.rt_generate.argtypes = [vp, C.POINTER(RtGenerateArgs)]
+    lib.rt_generate_stats.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     lib.rt_wav_length.restype = i64
     lib.rt_wav_length.argtypes = [vp, i32]
     lib.rt_code2wav.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, i64, C.POINTER(i64)]
@@ -458,6 +459,14 @@ class NativeModel:
             out.append(flat_codes[off: off + nfr[b]].clone())
             off += int(max_frames[b])
         return (out, tr) if trace else out
+
+    def generate_stats(self) -> dict:
+        """Figures of the last ``generate``: decode frames launched, rows, frames kept, row hand-overs to queued items."""
+        v = [C.c_int64() for _ in range(4)]
+        self.ctx.check(self.lib.rt_generate_stats(self.handle, *[C.byref(x) for x in v]), "rt_generate_stats")
+        run, rows, kept, swaps = (int(x.value) for x in v)
+        return {"frames_run": run, "rows": rows, "frames_kept": kept, "hand_overs": swaps,
+                "row_occupancy": kept / max(1, run * rows)}
 
     # ------------------------------------------------------------------ vocoder
     def wav_length(self, n_frames: int) -> int:

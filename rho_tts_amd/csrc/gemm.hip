@@ -702,6 +702,9 @@ int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (c
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
 int g_attn_mfma = 0;             // 1: the talker's decode attention runs its shared-prefix part on the matrix cores (attention_mfma.hip);
                                 // measured 16.6 us per launch against 13.3 us for the vector-unit kernel at batch 32 / 460 prefix rows, so off
+int g_handover_every = 4;       // queued items (n_items > rows): frames between two looks at the flags + row hand-overs.  Measured on the
+                                // 1.7B model, 512 / 64 ragged texts on 32 rows: 2 -> 487 / 445, 3 -> 489 / 445, 4 -> 491 / 447, 6 -> 485 / 445,
+                                // 8 -> 477 / 428, 12 -> 475 / 434 audio-s/s (a hand-over costs ~1.4 ms, a waiting row 0.13 ms per frame)
 int g_eos_check_every = 8;      // frames between two host looks at the device-side end-of-sequence flags (1 = every frame)
 int g_sync_parts = 0;           // 1: rt_generate waits for the stream after every frame part (bounds the dispatches in flight; profiling aid)
 int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)

@@ -79,6 +79,7 @@ extern int g_pred_nt;
 extern int g_decode_lanes;
 extern int g_sync_parts;
 extern int g_eos_check_every;
+extern int g_handover_every;
 extern int g_tile96;
 extern int g_conv_win;
 extern int g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
@@ -125,8 +126,10 @@ struct ColArgs {
 };
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)
+// src_rows / dst_rows (device, [M], optional): block i reads x row src_rows[i] and writes (tiled / rowsq) row dst_rows[i]
 int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr,
-                 bf16_t* a_tiled = nullptr, const float* norm_w = nullptr);
+                 bf16_t* a_tiled = nullptr, const float* norm_w = nullptr, const int32_t* src_rows = nullptr,
+                 const int32_t* dst_rows = nullptr);
 
 // decode-step input: x = add_vec + sum of n_src (<= 16) bf16 embedding rows (or one row of f32_table), emitted as tiled x,
 // tiled bf16(norm_w .* x) and rowsq - the fusion of launch_gather_sum / launch_gather_f32 with launch_rowsq
@@ -236,6 +239,7 @@ struct SampleArgs {
     // frame-indexed addressing for graph replay: when frame_ptr != nullptr the frame index is read from the device and
     // out / eos_flag / forced / logits_copy are advanced by frame * their stride; eos is allowed from min_frames on
     const int32_t* frame_ptr;
+    const int32_t* frame_off;  // [M] or null: the frame counter value at which row r's current item started (RNG / min_frames use *frame_ptr - frame_off[r])
     int64_t out_fs, eos_fs, forced_fs, copy_fs;
     int eos_live, min_frames;
     long long* stamps;         // debug: wall-clock (100 MHz) stamps of row 0 at the phase boundaries, or null

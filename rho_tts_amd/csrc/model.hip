@@ -70,6 +70,7 @@ __global__ void k_fill_i32(int32_t* p, int n, int v, int step_every, int step) {
 }  // namespace
 
 struct rt_model {
+    int64_t last_frames_run = 0, last_rows = 0, last_kept = 0, last_swaps = 0;   // rt_generate_stats
     rt_ctx* ctx = nullptr;
     rt_model_config cfg{};
     std::vector<Slot> slots;
@@ -520,16 +521,22 @@ int col_head(rt_model* m, const bf16_t* xa, const float* rowsq, int rowsq_n, int
 }
 
 // text_proj(text_embedding[ids]) -> f32 [n][H]
-int text_project(rt_model* m, const int32_t* d_ids, int n, float* out) {
+struct TextWs { bf16_t *e = nullptr, *h1 = nullptr; GatherSrc* d_src = nullptr; };   // optional caller-owned workspace (repeated calls)
+int alloc_text_ws(rt_model* m, int n, TextWs* w) {
+    RT_TRY(pool_arr(m, (size_t)n * m->cfg.text_hidden, &w->e));
+    RT_TRY(pool_arr(m, (size_t)n * m->cfg.text_hidden, &w->h1));
+    RT_TRY(pool_arr(m, 1, &w->d_src));
+    const GatherSrc src{TBL(m, "talker.text_embedding"), m->cfg.text_hidden};
+    RT_HIP(m->ctx, hipMemcpy(w->d_src, &src, sizeof(src), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+int text_project(rt_model* m, const int32_t* d_ids, int n, float* out, const TextWs* ws = nullptr) {
     rt_ctx* ctx = m->ctx;
     const rt_model_config& c = m->cfg;
-    bf16_t *e = nullptr, *h1 = nullptr;
-    RT_TRY(pool_arr(m, (size_t)n * c.text_hidden, &e));
-    RT_TRY(pool_arr(m, (size_t)n * c.text_hidden, &h1));
-    GatherSrc src{TBL(m, "talker.text_embedding"), c.text_hidden};
-    GatherSrc* d_src = nullptr;
-    RT_TRY(pool_arr(m, 1, &d_src));
-    RT_HIP(ctx, hipMemcpyAsync(d_src, &src, sizeof(src), hipMemcpyHostToDevice, ctx->stream));
+    TextWs own;
+    if (!ws) { RT_TRY(alloc_text_ws(m, n, &own)); ws = &own; }
+    bf16_t *e = ws->e, *h1 = ws->h1;
+    GatherSrc* d_src = ws->d_src;
     RT_TRY(launch_gather_sum(ctx, d_src, 1, d_ids, n, c.text_hidden, nullptr, nullptr, nullptr, nullptr, e));
     GemmA a; a.ptr = e; a.M = n; a.Cin = c.text_hidden;
     GemmEpi e1; e1.bias = VEC(m, "talker.tp_fc1_b"); e1.act = ACT_SILU; e1.out_bf16 = h1; e1.ldc = c.text_hidden;
@@ -1061,23 +1068,40 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     if (!m->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_generate: model not finalized");
     if (m->prefix_len < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: no voice set (rt_model_set_voice)");
     const rt_model_config& c = m->cfg;
-    const int B = A->n_items, G = c.n_groups, H = c.talker.hidden, Hp = c.predictor.hidden, Vc = c.codec_vocab, Vp = c.predictor_vocab;
-    if (B < 1 || B > c.max_batch) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: n_items %d outside 1..%d", B, c.max_batch);
+    // N items are decoded on B = min(N, max_batch) rows.  With N > B the first B items start on the rows and the others
+    // wait in a queue: whenever the host learns (every g_handover_every frames) that rows have finished, the next queued
+    // items take them over - their prompt suffixes are prefilled into the rows' KV slots between two frames, the rows'
+    // state / position base / RNG stream / repetition history are re-pointed - so that every weight pass keeps serving
+    // live rows.  An item's result depends only on (item id, seed): the same codes as in any static batch, up to the
+    // float32 summation order of its prompt prefill (whose GEMM shape depends on how many suffix rows are prefilled together).
+    const int N = A->n_items, G = c.n_groups, H = c.talker.hidden, Hp = c.predictor.hidden, Vc = c.codec_vocab, Vp = c.predictor_vocab;
+    if (N < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: n_items %d < 1", N);
+    const int B = std::min(N, c.max_batch);
+    const bool queued = N > B;
     if (!A->h_text_ids || !A->h_text_offsets || !A->h_max_frames || !A->h_item_ids || !A->h_codes || !A->h_n_frames)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: null array");
+    if (queued && (A->h_forced_codes || A->d_trace_talker || A->d_trace_predictor))
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: teacher forcing / logit traces need n_items <= max_batch (%d)", c.max_batch);
+    const int every = std::max(1, queued ? g_handover_every : g_eos_check_every);
     int T_max = 0, n_suffix = 0, max_suffix = 0;
-    for (int b = 0; b < B; ++b) {
+    int64_t budget_sum = 0;
+    for (int b = 0; b < N; ++b) {
         const int nt = A->h_text_offsets[b + 1] - A->h_text_offsets[b];
         if (nt < 0 || A->h_max_frames[b] < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: item %d has bad text or max_frames", b);
         T_max = std::max(T_max, A->h_max_frames[b]);
-        n_suffix += nt + 2;
+        if (b < B) n_suffix += nt + 2;
         max_suffix = std::max(max_suffix, nt + 2);
+        budget_sum += A->h_max_frames[b] + every;
     }
-    for (int i = 0; i < A->h_text_offsets[B]; ++i)
+    for (int i = 0; i < A->h_text_offsets[N]; ++i)
         if (A->h_text_ids[i] < 0 || A->h_text_ids[i] >= c.text_vocab) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: text id out of range");
     const int Lp = m->prefix_len;
-    if (Lp + max_suffix + T_max + 1 > c.max_positions)
-        return rt_fail(ctx, RT_ERR_LENGTH, "rt_generate: prompt length %d + %d frames exceeds max_positions %d", Lp + max_suffix, T_max, c.max_positions);
+    const int F_max = T_max;                               // the longest single item
+    // (a finished row keeps stepping until the host has seen its flag: up to `every` - 1 positions past its last frame)
+    if (Lp + max_suffix + F_max + (queued ? every : 0) + 1 > c.max_positions)
+        return rt_fail(ctx, RT_ERR_LENGTH, "rt_generate: prompt length %d + %d frames exceeds max_positions %d", Lp + max_suffix, F_max, c.max_positions);
+    // frame-counter budget: list scheduling finishes within sum / rows + longest (each item charged its wait for the next check)
+    if (queued) T_max = (int)std::min<int64_t>(budget_sum / B + F_max + every + 1, (int64_t)1 << 24);
     if (A->talker.do_sample && (A->talker.top_k < 1 || A->talker.top_k > 64 || !(A->talker.temperature > 0)))
         return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: sampling needs 1 <= top_k <= 64 and temperature > 0");
     if (A->predictor.do_sample && (A->predictor.top_k < 1 || A->predictor.top_k > 64 || !(A->predictor.temperature > 0)))
@@ -1087,49 +1111,75 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // ---- the voice prefix KV stays in its own slot: every sequence reads cache rows [0, Lp) from there (KvCache::prefix_slot)
     m->talker.kv.prefix_slot = m->prefix_slot();
     m->talker.kv.prefix_len = Lp;
-    // ---- suffix rows: [text tokens + tts_eos] x codec_pad, then (tts_pad, codec_bos)
-    std::vector<int32_t> s_tid(n_suffix + 1), s_cid((size_t)n_suffix * G, -1), s_slot(n_suffix), s_pos(n_suffix), last_row(B), P(B);
-    int r = 0;
-    for (int b = 0; b < B; ++b) {
-        const int o = A->h_text_offsets[b], nt = A->h_text_offsets[b + 1] - o;
-        for (int j = 0; j < nt + 2; ++j, ++r) {
-            s_tid[r] = j < nt ? A->h_text_ids[o + j] : (j == nt ? A->tts_eos_id : A->tts_pad_id);
-            s_cid[(size_t)r * G] = j <= nt ? A->codec_pad_id : A->codec_bos_id;
-            s_slot[r] = b;
-            s_pos[r] = Lp + j;
-        }
-        last_row[b] = r - 1;
-        P[b] = Lp + nt + 2;
-    }
-    s_tid[n_suffix] = A->tts_pad_id;  // extra row: projected tts_pad, added to every decode-step input
-    int32_t *d_tid, *d_cid, *d_slot, *d_pos, *d_last;
-    RT_TRY(pool_arr(m, n_suffix + 1, &d_tid));
-    RT_TRY(pool_arr(m, (size_t)n_suffix * G, &d_cid));
-    RT_TRY(pool_arr(m, n_suffix, &d_slot));
-    RT_TRY(pool_arr(m, n_suffix, &d_pos));
+    // ---- suffix rows: [text tokens + tts_eos] x codec_pad, then (tts_pad, codec_bos).  Row 0 of the id / embedding buffers
+    // is the projected tts_pad that every decode step adds to its input; the suffix rows of the items being prefilled follow.
+    const int S_cap = queued ? B * max_suffix : n_suffix;
+    struct Staging { std::vector<int32_t> tid, cid, slot, pos, last, dst; };
+    std::vector<std::unique_ptr<Staging>> staging;        // host sources of asynchronous uploads: alive until the call returns
+    std::vector<int32_t> P(N, 0);
+    int32_t *d_tid, *d_cid, *d_slot, *d_pos, *d_last, *d_dst;
+    RT_TRY(pool_arr(m, S_cap + 1, &d_tid));
+    RT_TRY(pool_arr(m, (size_t)S_cap * G, &d_cid));
+    RT_TRY(pool_arr(m, S_cap, &d_slot));
+    RT_TRY(pool_arr(m, S_cap, &d_pos));
     RT_TRY(pool_arr(m, B, &d_last));
-    RT_HIP(ctx, hipMemcpyAsync(d_tid, s_tid.data(), (n_suffix + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_cid, s_cid.data(), (size_t)n_suffix * G * 4, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_slot, s_slot.data(), n_suffix * 4, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_pos, s_pos.data(), n_suffix * 4, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(d_last, last_row.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_TRY(pool_arr(m, B, &d_dst));
     float *temb, *x, *hn_all_f32;
-    RT_TRY(pool_arr(m, (size_t)(n_suffix + 1) * H, &temb));
-    RT_TRY(text_project(m, d_tid, n_suffix + 1, temb));
-    const float* pad_t = temb + (size_t)n_suffix * H;
-    RT_TRY(pool_arr(m, (size_t)n_suffix * H, &x));
-    RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_cid, n_suffix, H, nullptr, temb, nullptr, x, nullptr));
-    RT_TRY(pool_arr(m, (size_t)n_suffix * H, &hn_all_f32));
+    RT_TRY(pool_arr(m, (size_t)(S_cap + 1) * H, &temb));
+    RT_TRY(pool_arr(m, (size_t)S_cap * H, &x));
+    RT_TRY(pool_arr(m, (size_t)S_cap * H, &hn_all_f32));
+    const float* pad_t = temb;
+    StackWs w_prefill;
+    RT_TRY(alloc_stack_ws(m, c.talker, S_cap, &w_prefill));
+    TextWs w_text;
+    RT_TRY(alloc_text_ws(m, S_cap + 1, &w_text));
+    // prefill the suffixes of `items` into the KV slots of `rows`; on return x holds the residual stream, d_last / d_dst
+    // the (last suffix row, decode row) of each item
+    auto prefill = [&](const std::vector<int>& items, const std::vector<int>& rows, bool first) -> int {
+        const int k = (int)items.size();
+        int n = 0;
+        for (int it : items) n += A->h_text_offsets[it + 1] - A->h_text_offsets[it] + 2;
+        if (n > S_cap) return rt_fail(ctx, RT_ERR_STATE, "rt_generate: prefill of %d rows exceeds its workspace (%d)", n, S_cap);
+        staging.emplace_back(new Staging());
+        Staging& st = *staging.back();
+        std::vector<int32_t>&s_tid = st.tid, &s_cid = st.cid, &s_slot = st.slot, &s_pos = st.pos, &last_row = st.last, &dst_row = st.dst;
+        s_tid.assign(n + 1, 0); s_cid.assign((size_t)n * G, -1); s_slot.assign(n, 0); s_pos.assign(n, 0); last_row.assign(k, 0); dst_row.assign(k, 0);
+        s_tid[0] = A->tts_pad_id;
+        int r = 0;
+        for (int i = 0; i < k; ++i) {
+            const int it = items[i], o = A->h_text_offsets[it], nt = A->h_text_offsets[it + 1] - o;
+            for (int j = 0; j < nt + 2; ++j, ++r) {
+                s_tid[1 + r] = j < nt ? A->h_text_ids[o + j] : (j == nt ? A->tts_eos_id : A->tts_pad_id);
+                s_cid[(size_t)r * G] = j <= nt ? A->codec_pad_id : A->codec_bos_id;
+                s_slot[r] = rows[i];
+                s_pos[r] = Lp + j;
+            }
+            last_row[i] = r - 1;
+            dst_row[i] = rows[i];
+            P[it] = Lp + nt + 2;
+        }
+        RT_HIP(ctx, hipMemcpyAsync(d_tid, s_tid.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_cid, s_cid.data(), (size_t)n * G * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_slot, s_slot.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_pos, s_pos.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_last, last_row.data(), k * 4, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(d_dst, dst_row.data(), k * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (first) RT_TRY(text_project(m, d_tid, n + 1, temb, &w_text));  // (the tts_pad row is projected once)
+        else RT_TRY(text_project(m, d_tid + 1, n, temb + H, &w_text));
+        RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, d_cid, n, H, nullptr, temb + H, nullptr, x, nullptr));
+        RT_TRY(stack_forward(m, m->talker, w_prefill, x, n, d_slot, d_pos, 0, nullptr, hn_all_f32));
+        return RT_OK;
+    };
     {
-        StackWs w;
-        RT_TRY(alloc_stack_ws(m, c.talker, n_suffix, &w));
-        RT_TRY(stack_forward(m, m->talker, w, x, n_suffix, d_slot, d_pos, 0, nullptr, hn_all_f32));
+        std::vector<int> items(B), rows(B);
+        for (int b = 0; b < B; ++b) { items[b] = b; rows[b] = b; }
+        RT_TRY(prefill(items, rows, true));
     }
     // ---- decode state.  The batch is cut into `lanes` groups of consecutive items, each decoding on its own stream with
     // its own workspaces: a decode step is a chain of ~600 short dependent kernels whose cost is latency, not bytes, so two
     // chains in flight overlap each other's launch/drain gaps (items are independent: same results for any lane count).
     int32_t *d_codes, *d_eos, *d_forced = nullptr;
-    RT_TRY(pool_arr(m, (size_t)T_max * B * G, &d_codes));
+    RT_TRY(pool_arr(m, (size_t)T_max * B * G, &d_codes));      // [frame counter][row][group]
     RT_TRY(pool_arr(m, (size_t)T_max * B, &d_eos));
     RT_HIP(ctx, hipMemsetAsync(d_codes, 0, (size_t)T_max * B * G * 4, ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(d_eos, 0, (size_t)T_max * B * 4, ctx->stream));
@@ -1166,7 +1216,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         hipStream_t stream = nullptr;
         float *xt = nullptr, *hn_f32 = nullptr, *xp = nullptr, *logits = nullptr, *rowsq_t = nullptr, *rowsq_p = nullptr;
         bf16_t *hn = nullptr, *hn_p = nullptr;
-        int32_t *d_slot_b = nullptr, *d_pos_b = nullptr, *d_pos_p2 = nullptr, *d_zero_pos = nullptr, *d_frame = nullptr;
+        int32_t *d_slot_b = nullptr, *d_pos_b = nullptr, *d_pos_p2 = nullptr, *d_zero_pos = nullptr, *d_frame = nullptr, *d_frame_off = nullptr;
         int64_t* d_items = nullptr;
         uint8_t* d_seen = nullptr;
         DecWs dwt, dwp;
@@ -1174,7 +1224,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         bool done = false;
     };
     int n_lanes = std::max(1, std::min(g_decode_lanes, 8));
-    if (!col || m->prof) n_lanes = 1;                      // (per-launch profiling wants undisturbed launches)
+    if (!col || m->prof || queued) n_lanes = 1;            // (per-launch profiling wants undisturbed launches)
+    if (queued && !col) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_generate: queued items (n_items %d > %d rows) need the column decode path", N, B);
     while (n_lanes > 1 && B / n_lanes < 8) --n_lanes;      // a lane narrower than 8 rows only multiplies the weight traffic
     std::vector<Lane> lanes(n_lanes);
     hipStream_t main_stream = ctx->stream;
@@ -1209,6 +1260,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         RT_TRY(pool_arr(m, n, &ln.d_items));
         RT_TRY(pool_arr(m, (size_t)n * Vc, &ln.d_seen));
         RT_TRY(pool_arr(m, 1, &ln.d_frame));
+        RT_TRY(pool_arr(m, n, &ln.d_frame_off));
+        RT_HIP(ctx, hipMemsetAsync(ln.d_frame_off, 0, n * 4, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(ln.d_seen, 0, (size_t)n * Vc, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(ln.d_zero_pos, 0, n2 * 4, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(ln.d_frame, 0, 4, ctx->stream));
@@ -1253,7 +1306,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         sa.forced = d_forced ? d_forced + ln.b0 : nullptr; sa.forced_fs = (int64_t)G * B;
         sa.out = codes; sa.out_stride = G; sa.out_fs = codes_fs; sa.eos_token = c.codec_eos_id; sa.eos_flag = d_eos + ln.b0; sa.eos_fs = B;
         sa.logits_copy = A->d_trace_talker ? A->d_trace_talker + (size_t)ln.b0 * Vc : nullptr; sa.copy_fs = (int64_t)B * Vc;
-        sa.frame_ptr = ln.d_frame; sa.eos_live = A->ignore_eos ? 0 : 1; sa.min_frames = A->min_frames;
+        sa.frame_ptr = ln.d_frame; sa.frame_off = ln.d_frame_off; sa.eos_live = A->ignore_eos ? 0 : 1; sa.min_frames = A->min_frames;
         RT_TRY(launch_sample(ctx, sa));
         // predictor: rows [0,n) = past hidden (pos 0), rows [n,2n) = embedding of code 0 (pos 1)
         if (m->has_mtp()) {
@@ -1293,7 +1346,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             sp.out = codes + q + 1; sp.out_stride = G; sp.out_fs = codes_fs; sp.eos_token = -1; sp.eos_flag = nullptr; sp.eos_fs = 0;
             sp.logits_copy = A->d_trace_predictor ? A->d_trace_predictor + ((size_t)q * B + ln.b0) * Vp : nullptr;
             sp.copy_fs = (int64_t)(G - 1) * B * Vp;
-            sp.frame_ptr = ln.d_frame; sp.eos_live = 0; sp.min_frames = 0;
+            sp.frame_ptr = ln.d_frame; sp.frame_off = ln.d_frame_off; sp.eos_live = 0; sp.min_frames = 0;
             const bool fuse_emb = col && m->has_mtp() && g_fuse_sample_embed && q < G - 2 && Vp <= 4096 && Hp % 8 == 0;
             if (fuse_emb) {     // the sampler itself turns the drawn code into the next pass's input
                 sp.emb_table = m->proj_emb[q]; sp.emb_H = Hp; sp.emb_norm_w = m->pred.L[0].ln1; sp.emb_rowsq = ln.rowsq_p; sp.emb_rowsq_n = NTp;
@@ -1350,7 +1403,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             mix((uint64_t)(uintptr_t)p);
         for (const Lane& ln : lanes)
             for (const void* p : {(const void*)ln.xt, (const void*)ln.xp, (const void*)ln.logits, (const void*)ln.d_seen, (const void*)ln.d_frame,
-                                  (const void*)ln.d_items, (const void*)ln.d_slot_b, (const void*)ln.d_pos_b, (const void*)ln.d_pos_p2,
+                                  (const void*)ln.d_frame_off, (const void*)ln.d_items, (const void*)ln.d_slot_b, (const void*)ln.d_pos_b, (const void*)ln.d_pos_p2,
                                   (const void*)ln.d_zero_pos, (const void*)ln.rowsq_t, (const void*)ln.rowsq_p, (const void*)ln.dwt.xT,
                                   (const void*)ln.dwp.xT, (const void*)ln.dwt.xa, (const void*)ln.dwp.xa, (const void*)ln.dwt.qkv,
                                   (const void*)ln.dwp.qkv, (const void*)ln.dwt.act, (const void*)ln.dwp.act, (const void*)ln.wt.slabs,
@@ -1403,35 +1456,81 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         for (Lane& ln : lanes) RT_HIP(ctx, hipStreamWaitEvent(ln.stream, m->fork_event, 0));
     }
     std::vector<int32_t> eos_host((size_t)T_max * B, 0);
-    std::vector<char> done(B, 0);
-    std::vector<int> produced(B, 0);
+    std::vector<int> produced(N, 0), start(N, 0), item_row(N, -1);   // per item: frames kept, first frame-counter value, row
+    std::vector<char> finished(N, 0);
+    std::vector<int> row_item(B);                          // item on each row, -1 = idle
+    for (int b = 0; b < B; ++b) { row_item[b] = b; item_row[b] = b; }
+    int next_item = B, n_finished = 0;
+    int64_t n_swaps = 0;
     int frames_run = 0;
     bool cancelled = false;
-    // End-of-sequence is decided on the device (the sampler writes one flag per item and frame); the host only needs the
-    // flags to know when to STOP launching, so it fetches them every `g_eos_check_every` frames instead of stalling the
-    // launch queue with a copy + wait per frame.  Frames launched past an item's end are wasted work on finished rows (the
-    // results are cut at the flag), at most g_eos_check_every - 1 of them at the very end of the batch.
-    const int eos_every = A->ignore_eos ? 0 : std::max(1, g_eos_check_every);
-    std::vector<int> lane_frames(n_lanes, 0);              // frame budget of a lane = its longest item
-    for (int l = 0; l < n_lanes; ++l)
+    // End-of-sequence is decided on the device (the sampler writes one flag per row and frame); the host only needs the
+    // flags to know when to STOP launching (or to hand a row to the next queued item), so it fetches them every
+    // `g_eos_check_every` frames instead of stalling the launch queue with a copy + wait per frame.  Frames launched past an
+    // item's end are wasted work on a finished row (the results are cut at the flag), at most g_eos_check_every - 1 of them.
+    const int eos_every = A->ignore_eos ? 0 : every;
+    std::vector<int> lane_frames(n_lanes, 0);              // frame budget of a lane = its longest item (static batches)
+    for (int l = 0; l < n_lanes; ++l) {
         for (int bb = lanes[l].b0; bb < lanes[l].b0 + lanes[l].n; ++bb) lane_frames[l] = std::max(lane_frames[l], A->h_max_frames[bb]);
-    int checked = 0;                                       // frames whose flags have been applied to done / produced
+        if (queued) lane_frames[l] = T_max;
+    }
+    int checked = 0;                                       // frames whose flags have been applied
     auto apply_frames = [&](int upto) {                    // bookkeeping of frames [checked, upto), in order
         for (int t = checked; t < upto; ++t)
-            for (int bb = 0; bb < B; ++bb) {
-                if (done[bb]) continue;
-                if (eos_host[(size_t)t * B + bb]) done[bb] = 1;
-                else if (++produced[bb] >= A->h_max_frames[bb]) done[bb] = 1;
+            for (int r = 0; r < B; ++r) {
+                const int it = row_item[r];
+                if (it < 0 || t < start[it]) continue;
+                bool fin = false;
+                if (eos_host[(size_t)t * B + r]) fin = true;
+                else if (++produced[it] >= A->h_max_frames[it]) fin = true;
+                if (fin) { finished[it] = 1; row_item[r] = -1; ++n_finished; }
             }
         checked = upto;
-        bool all = true;
         for (Lane& ln : lanes) {
             bool lane_done = true;
-            for (int bb = ln.b0; bb < ln.b0 + ln.n; ++bb) lane_done = lane_done && done[bb];
-            ln.done = lane_done;
-            all = all && lane_done;
+            for (int r = ln.b0; r < ln.b0 + ln.n; ++r) lane_done = lane_done && row_item[r] < 0;
+            ln.done = lane_done && next_item >= N;
         }
-        return all;
+        return n_finished == N;
+    };
+    // idle rows take the next queued items; the caller has launched part B of frame t1 - 1, so the new items' first frame is t1
+    std::vector<int32_t> h_pos_b(P.begin(), P.begin() + B), h_off(B, 0);
+    std::vector<int64_t> h_items(A->h_item_ids, A->h_item_ids + B);
+    std::vector<char> parked(B, 0);
+    auto swap_in = [&](int t1) -> int {
+        Lane& ln = lanes[0];
+        std::vector<int> items, rows;
+        bool dirty = false;
+        for (int r = 0; r < B; ++r) {
+            if (row_item[r] >= 0) continue;
+            if (next_item < N) {
+                const int it = next_item++;
+                items.push_back(it); rows.push_back(r);
+                row_item[r] = it; item_row[it] = r; start[it] = t1; parked[r] = 0;
+            } else if (!parked[r]) {                       // nothing left for this row: restart its positions so that they stay in range
+                parked[r] = 1; h_pos_b[r] = Lp - t1; dirty = true;
+            }
+        }
+        if (!items.empty()) {
+            RT_TRY(prefill(items, rows, false));
+            const int k = (int)items.size();
+            // rows' state <- residual stream of each new item's last prompt position (what the initial hand-over does for all rows)
+            RT_TRY(launch_rowsq(ctx, x, k, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.norm, d_last, d_dst));
+            for (int i = 0; i < k; ++i) {
+                const int r = rows[i], it = items[i];
+                h_pos_b[r] = P[it] - t1; h_off[r] = t1; h_items[r] = A->h_item_ids[it];
+                RT_HIP(ctx, hipMemsetAsync(ln.d_seen + (size_t)r * Vc, 0, Vc, ctx->stream));
+            }
+            dirty = true;
+            ++n_swaps;
+        }
+        if (dirty) {
+            RT_HIP(ctx, hipMemcpyAsync(ln.d_pos_b, h_pos_b.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
+            RT_HIP(ctx, hipMemcpyAsync(ln.d_frame_off, h_off.data(), B * 4, hipMemcpyHostToDevice, ctx->stream));
+            RT_HIP(ctx, hipMemcpyAsync(ln.d_items, h_items.data(), B * 8, hipMemcpyHostToDevice, ctx->stream));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the three host arrays are rewritten by the next hand-over)
+        }
+        return RT_OK;
     };
     for (int t = 0; t < T_max; ++t) {
         if (A->h_cancel_flag && *A->h_cancel_flag) { cancelled = true; break; }
@@ -1446,9 +1545,10 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
         ctx->stream = main_stream;
         frames_run = t + 1;
         bool all_done;
+        const bool check = (t + 1) % every == 0 || t + 1 == T_max;
         if (eos_every == 0) {
             all_done = apply_frames(t + 1);                // no flags to wait for: the frame budgets alone decide
-        } else if ((t + 1) % eos_every == 0 || t + 1 == T_max) {
+        } else if (check) {
             for (Lane& ln : lanes) {
                 if (ln.done) continue;
                 RT_HIP(ctx, hipMemcpyAsync(eos_host.data() + (size_t)checked * B, d_eos + (size_t)checked * B, (size_t)(t + 1 - checked) * B * 4,
@@ -1471,6 +1571,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         }
         ctx->stream = main_stream;
+        if (queued && check) RT_TRY(swap_in(t + 1));
     }
     if (!cancelled && checked < frames_run) {              // (cancelled runs report nothing)
         if (eos_every) {
@@ -1493,14 +1594,27 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pool_release_all(m);
     if (cancelled) return rt_fail(ctx, RT_ERR_CANCELLED, "rt_generate: cancelled after %d frames", frames_run);
+    if (n_finished != N) return rt_fail(ctx, RT_ERR_STATE, "rt_generate: %d of %d items unfinished after %d frames", N - n_finished, N, frames_run);
     size_t off = 0;
-    for (int b = 0; b < B; ++b) {
-        const int n = std::min(produced[b], frames_run);
-        A->h_n_frames[b] = n;
+    int64_t kept = 0;
+    for (int it = 0; it < N; ++it) {
+        const int n = std::min(produced[it], frames_run - start[it]), r = item_row[it];
+        A->h_n_frames[it] = n;
+        kept += n;
         for (int t = 0; t < n; ++t)
-            for (int q = 0; q < G; ++q) A->h_codes[(off + t) * G + q] = codes_host[((size_t)t * B + b) * G + q];
-        off += A->h_max_frames[b];
+            for (int q = 0; q < G; ++q) A->h_codes[(off + t) * G + q] = codes_host[((size_t)(start[it] + t) * B + r) * G + q];
+        off += A->h_max_frames[it];
     }
+    m->last_frames_run = frames_run; m->last_rows = B; m->last_kept = kept; m->last_swaps = n_swaps;
+    return RT_OK;
+}
+
+int rt_generate_stats(rt_model* m, int64_t* frames_run, int64_t* rows, int64_t* frames_kept, int64_t* hand_overs) {
+    if (!m) return RT_ERR_INVALID;
+    if (frames_run) *frames_run = m->last_frames_run;
+    if (rows) *rows = m->last_rows;
+    if (frames_kept) *frames_kept = m->last_kept;
+    if (hand_overs) *hand_overs = m->last_swaps;
     return RT_OK;
 }
 

@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int 
 // re-tiles the row into the fragment layout (common.h tile_off) the decode GEMMs read.
 __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int H, float* __restrict__ rowsq, int rowsq_n,
                                                float* __restrict__ x_tiled, bf16_t* __restrict__ a_tiled,
-                                               const float* __restrict__ norm_w) {
+                                               const float* __restrict__ norm_w, const int32_t* __restrict__ src_rows,
+                                               const int32_t* __restrict__ dst_rows) {
     __shared__ float sh[4];
-    const int64_t row = blockIdx.x;
-    const f4_t* xr = reinterpret_cast<const f4_t*>(x + row * H);
+    // (optional row maps: block i reads row src_rows[i] of x and writes decode row dst_rows[i] - a queued item taking over a row)
+    const int64_t row = dst_rows ? dst_rows[blockIdx.x] : blockIdx.x;
+    const f4_t* xr = reinterpret_cast<const f4_t*>(x + (int64_t)(src_rows ? src_rows[blockIdx.x] : blockIdx.x) * H);
     float ss = 0.f;
     for (int i = threadIdx.x; i < (H >> 2); i += 256) {
         const f4_t v = xr[i];
@@ -421,9 +423,9 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
 }
 
 int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled, bf16_t* a_tiled,
-                 const float* norm_w) {
+                 const float* norm_w, const int32_t* src_rows, const int32_t* dst_rows) {
     if (M <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
+    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w, src_rows, dst_rows);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -39,12 +39,13 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs A) {
     if (A.seed_ptr) A.seed = *A.seed_ptr;
     if (A.frame_ptr) {     // graph replay: frame index and frame-strided buffers resolved on the device
         const int f = *A.frame_ptr;
-        A.frame = f;
+        const int fr = f - (A.frame_off ? A.frame_off[row] : 0);   // the row's own frame (rows are re-assigned to queued items)
+        A.frame = fr;
         A.out += (int64_t)f * A.out_fs;
         if (A.eos_flag) A.eos_flag += (int64_t)f * A.eos_fs;
         if (A.forced) A.forced += (int64_t)f * A.forced_fs;
         if (A.logits_copy) A.logits_copy += (int64_t)f * A.copy_fs;
-        A.allow_token = (A.eos_live && f >= A.min_frames) ? A.eos_token : -1;
+        A.allow_token = (A.eos_live && fr >= A.min_frames) ? A.eos_token : -1;
     }
     uint8_t* seen = A.seen ? A.seen + (int64_t)row * V : nullptr;
 
@@ -250,12 +251,13 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
     if (A.seed_ptr) A.seed = *A.seed_ptr;
     if (A.frame_ptr) {     // graph replay: frame index and frame-strided buffers resolved on the device
         const int f = *A.frame_ptr;
-        A.frame = f;
+        const int fr = f - (A.frame_off ? A.frame_off[row] : 0);   // the row's own frame (rows are re-assigned to queued items)
+        A.frame = fr;
         A.out += (int64_t)f * A.out_fs;
         if (A.eos_flag) A.eos_flag += (int64_t)f * A.eos_fs;
         if (A.forced) A.forced += (int64_t)f * A.forced_fs;
         if (A.logits_copy) A.logits_copy += (int64_t)f * A.copy_fs;
-        A.allow_token = (A.eos_live && f >= A.min_frames) ? A.eos_token : -1;
+        A.allow_token = (A.eos_live && fr >= A.min_frames) ? A.eos_token : -1;
     }
     uint8_t* seen = A.seen ? A.seen + (int64_t)row * V : nullptr;
 

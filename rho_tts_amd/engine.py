@@ -175,18 +175,40 @@ class Engine:
         return bucket_batches(frames, self.max_batch)
 
     def synthesize(self, texts: Sequence[str], seed: int = 789, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
-                   max_frames: Optional[Sequence[int]] = None, stats: Optional[dict] = None) -> List[torch.Tensor]:
-        """Raw waveforms (GPU float32, 1-D) for a batch of texts, ``max_batch`` at a time, in the order of ``texts``.
+                   max_frames: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
+                   continuous: Optional[bool] = None, plan_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """Raw waveforms (GPU float32, 1-D) for any number of texts, in the order of ``texts``.
         The RNG stream of a text is its ``item_ids`` entry (default: its index), so the result does not depend on how the
-        texts are cut into batches.  ``stats`` (optional dict) receives the padding efficiency of the cut."""
+        texts are scheduled.  More texts than ``max_batch`` are decoded with continuous batching (``continuous``, default on
+        when the decode rows allow it): ONE rt_generate call with the texts queued longest first, finished rows handed to the
+        next queued text, then the codec decoder over batches sorted by the lengths actually produced.  ``continuous=False``
+        cuts static batches bucketed by frame budget instead (plan_batches).  ``plan_frames``: the length ESTIMATES the
+        schedule is planned with when they differ from the budgets ``max_frames`` (a real checkpoint ends at end-of-sequence,
+        somewhere below its budget).  ``stats`` (optional dict) receives kept / launched row-frames of the schedule."""
         n = len(texts)
         ids = list(item_ids) if item_ids is not None else list(range(n))
         if max_frames is not None:
             frames = [int(f) for f in max_frames]
         else:
             frames = [self.frames_for(t, len(self.tokenizer.encode(t))) for t in texts]
+        plan = [int(f) for f in plan_frames] if plan_frames is not None else frames
         wavs: List[Optional[torch.Tensor]] = [None] * n
-        batches = self.plan_batches(frames)
+        if continuous is None:
+            continuous = n > self.max_batch and self.max_batch <= 32       # (the column decode path serves <= 32 rows)
+        if continuous and n > self.max_batch:
+            order = sorted(range(n), key=lambda i: (-plan[i], i))          # longest first: short items fill the tail of the schedule
+            codes = self.generate_codes([texts[i] for i in order], seed, [ids[i] for i in order], cancel_flag, [frames[i] for i in order])
+            st = self.model.generate_stats()
+            by_len = sorted(range(n), key=lambda j: (-int(codes[j].shape[0]), j))
+            for j, w in zip(by_len, self.vocode([codes[j] for j in by_len])):
+                wavs[order[j]] = w
+            if stats is not None:
+                stats["frames"] = stats.get("frames", 0) + st["frames_kept"]
+                stats["padded_frames"] = stats.get("padded_frames", 0) + st["frames_run"] * st["rows"]
+                stats["batches"] = stats.get("batches", 0) + 1
+                stats["hand_overs"] = stats.get("hand_overs", 0) + st["hand_overs"]
+            return wavs  # type: ignore[return-value]
+        batches = self.plan_batches(plan)
         for idx in batches:
             codes = self.generate_codes([texts[i] for i in idx], seed, [ids[i] for i in idx], cancel_flag, [frames[i] for i in idx])
             for i, w in zip(idx, self.vocode(codes)):

@@ -428,6 +428,13 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
             return float(eng.frames_for(segment, len(eng.tokenizer.encode(segment))))
         return float(max(1, len(segment.split())))
 
+    def _cut_batches(self, todo: List[int], work, bs: int) -> List[List[int]]:
+        """The engine decodes any number of segments on its ``batch_size`` rows with continuous batching (finished rows are handed
+        to the next queued segment, Engine.synthesize): the whole work list goes down in one call instead of being cut here."""
+        if len(todo) > bs and bs <= 32:
+            return [list(todo)]
+        return super()._cut_batches(todo, work, bs)
+
     # ---------------------------------------------------------------- provider contract
     def _generate_audio(self, text: Union[str, List[str]], **kwargs) -> Union[torch.Tensor, List[torch.Tensor]]:
         single = isinstance(text, str)

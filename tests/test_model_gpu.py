@@ -398,3 +398,47 @@ def test_voice_switch_does_not_replay_stale_graphs(models):
         valid[:n, b] = True
     err = (tr_graph["talker"][:T].cpu() - t_o)[valid][:, :V0].abs().max()
     assert float(err) <= 0.04 * float(t_o[valid][:, :V0].std()), float(err)
+
+
+@pytest.mark.parametrize("preset", ["tiny", "small"])
+def test_queued_items_take_over_finished_rows(ctx, preset):
+    """Continuous batching (rt_generate with n_items > max_batch): 13 ragged items on 4 decode rows.  Every item must come
+    out exactly as it does alone on row 0 of a one-item call - same RNG stream (item id, ITS frame number), fresh repetition
+    history, its own positions - whatever row it landed on and whenever it started; with fixed budgets, with live (sampled)
+    end-of-sequence, and for every flag-polling period.  The oracle is not needed: 'alone' is already pinned to it above."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg = config.PRESETS[preset]()
+    nm, _ = build(ctx, cfg, max_batch=4)
+    try:
+        set_voice(nm, make_voice(cfg, True))
+        g = torch.Generator().manual_seed(17)
+        n = 13
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(k),), generator=g)] for k in torch.randint(1, 9, (n,), generator=g)]
+        frames = [int(v) for v in torch.randint(3, 29, (n,), generator=g)]
+        ids = [100 + 7 * i for i in range(n)]
+        fixed = RtSampling(1, 0.9, 50, 1.0, 1.05)                      # repetition penalty on: the history must be reset per item
+        live = RtSampling(1, 1.5, 64, 1.0, 1.0)                        # hot sampling over the full top-k: end-of-sequence gets drawn
+        alone_fixed = [nm.generate([t], [f], fixed, seed=5, item_ids=[i])[0] for t, f, i in zip(texts, frames, ids)]
+        alone_live = [nm.generate([t], [f], live, seed=6, item_ids=[i], ignore_eos=False, min_frames=2)[0] for t, f, i in zip(texts, frames, ids)]
+        if preset == "tiny":                                            # (the larger vocabulary of `small` rarely has EOS in its top-64)
+            assert any(a.shape[0] < f for a, f in zip(alone_live, frames)), "no item ended early: the live case tests nothing"
+        for every in (4, 1, 7):
+            nm.lib.rt_debug_tune(1700 + every, 0)
+            got = nm.generate(texts, frames, fixed, seed=5, item_ids=ids)
+            st = nm.generate_stats()
+            assert [c.shape[0] for c in got] == frames
+            assert all(torch.equal(a, b) for a, b in zip(got, alone_fixed)), every
+            assert st["rows"] == 4 and st["frames_kept"] == sum(frames) and st["hand_overs"] >= 2
+            # list scheduling: no worse than sum / rows + longest (+ the polling slack per item)
+            assert st["frames_run"] <= (sum(frames) + n * every) // 4 + max(frames) + every + 1
+            got = nm.generate(texts, frames, live, seed=6, item_ids=ids, ignore_eos=False, min_frames=2)
+            assert all(torch.equal(a, b) for a, b in zip(got, alone_live)), every
+            assert nm.generate_stats()["frames_kept"] == sum(a.shape[0] for a in alone_live)
+        # a static batch afterwards still works (the graphs of the queued shape are not replayed for it)
+        again = nm.generate(texts[:4], frames[:4], fixed, seed=5, item_ids=ids[:4])
+        assert all(torch.equal(a, b) for a, b in zip(again, alone_fixed[:4]))
+        with pytest.raises(ValueError):                                 # teacher forcing is per frame counter: static batches only
+            nm.generate(texts, frames, fixed, forced_codes=[torch.zeros(f, cfg.n_groups, dtype=torch.int64) for f in frames])
+    finally:
+        nm.lib.rt_debug_tune(1704, 0)
+        nm.close()

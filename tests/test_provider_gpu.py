@@ -132,7 +132,10 @@ def test_generate_through_the_factory(tiny_provider, tmp_path):
 def test_batched_equals_one_at_a_time(tiny_provider):
     p = tiny_provider
     texts = ["Alpha beta gamma delta", "One two", "A somewhat longer piece of text to speak here"]
+    # 3 texts: one static batch.  11 texts on 4 rows: ONE continuous-batching call (finished rows handed to queued texts)
+    texts = texts + [" ".join(["word"] * k) + f" number {k}" for k in (9, 1, 14, 3, 6, 2, 11, 5)]
     both = p.generate(texts)
+    assert p._engine.model.generate_stats()["hand_overs"] >= 1
     p.batch_size = 1
     try:
         single = p.generate(texts)
