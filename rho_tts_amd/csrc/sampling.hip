@@ -217,35 +217,30 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// k-th largest of the wave's NQ x 64 keys: bit-serial search for the largest pivot with count(key >= pivot) >= k.  Per
-// (register, bit) the vector unit does ONE compare against a scalar pivot; counting and the decision are SALU.  Stops as
-// soon as a pivot separates exactly k keys (`exact`: the top k are key >= result); after all 32 bits the result is the
-// k-th largest key itself and equal keys may straddle the cut.  Needs 1 <= k <= number of non-zero keys.
-template <int NQ>
-__device__ __forceinline__ unsigned wave_kth_key(const unsigned (&key)[NQ], int k, bool& exact) {
-    unsigned prefix = 0;
-    exact = false;
-    for (unsigned bm = 0x80000000u; bm != 0u; bm >>= 1) {
-        const unsigned pivot = prefix | bm;
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) cnt += __popcll(__ballot(key[j] >= pivot));
-        if (cnt >= k) {
-            prefix = pivot;
-            if (cnt == k) { exact = true; break; }
-        }
-    }
-    return prefix;
-}
 __device__ __forceinline__ float lane_f32(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 __device__ __forceinline__ int lane_i32(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 
-template <int NV>
-__global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
-    __shared__ Cand wc[4][64];
-    __shared__ int wcount[4];
-    __shared__ float sh_f[4];
-    __shared__ int sh_i[4];
+__device__ __forceinline__ float okey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// NW waves, NV values per thread: element j of thread (w, lane) has index (w * NV + j) * 64 + lane, so that inside a wave
+// the index grows with (j, lane) and ties are resolved by position = by lowest index.
+//   phase 1  every wave narrows ITS keys down to a superset of its own top-k: the bit-serial pivot search stops as soon as
+//            at most 64 keys are >= the pivot (12-17 of the 32 bits on random logits) - no exact k-th key is needed here;
+//   prune    a wave with >= k keys above its pivot proves that the global k-th key is >= that pivot: T = the largest such
+//            pivot, and everything below T is dropped (typically ~100 candidates survive out of NW x 64);
+//   phase 2  every surviving candidate counts the candidates ahead of it under the unique 64-bit key (value desc, index asc):
+//            that rank is at once the exact top-k selection (rank < k, ties to the lowest indices) and the sort order;
+//   walk     wave 0 holds candidate r on lane r and evaluates softmax / top-p / inverse CDF in oracle/sampling.py's order.
+template <int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) unsigned long long ckey[NW * 64];
+    __shared__ unsigned long long sorted[64];
+    __shared__ __attribute__((aligned(16))) unsigned hist[1024];
+    __shared__ unsigned wpre[NW];
+    __shared__ int wcnt[NW];
+    __shared__ float sh_f[NW];
+    __shared__ int sh_i[NW];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, V = A.V;
     const int64_t slab_stride = (int64_t)A.M * V;
     if (A.seed_ptr) A.seed = *A.seed_ptr;
@@ -261,8 +256,6 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
     }
     uint8_t* seen = A.seen ? A.seen + (int64_t)row * V : nullptr;
 
-    // element j of this thread has index w*64*NV... no: idx = (w * NV + j) * 64 + lane, so that inside a wave the index
-    // grows with (j, lane): ties at the selection threshold are then resolved by position = by lowest index
     if (A.stamps && row == 0 && tid == 0) A.stamps[0] = wall_clock64();
     float v[NV];
     unsigned key[NV];
@@ -298,7 +291,7 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
             if (A.do_sample) l = __fdiv_rn(l, A.temperature);
         }
         v[j] = l;
-        key[j] = okey(l);
+        key[j] = valid[j] ? okey(l) : 0u;          // (okey(-inf) = 0x007FFFFF: every valid key is > 0)
     }
 
     if (A.stamps && row == 0 && tid == 0) A.stamps[1] = wall_clock64();
@@ -311,98 +304,160 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
     } else if (A.do_sample) {
         if (A.stamps && row == 0 && tid == 0) A.stamps[2] = wall_clock64();
         const int k = A.top_k < V ? A.top_k : V;
-        // ---- phase 1: this wave's own top-k (equal keys at the cut: lowest positions = lowest indices first)
-        int n_valid = 0;
+        // ---- fast path: ONE histogram over the distance from the row maximum.  d = max - v is monotone in v, and the top
+        // 11 bits of the float d (exponent + 2 mantissa bits) are a log-scale bin, 19 % wide relative to the distance: the
+        // bins up to the one where the running count reaches k hold a superset of the top-k that is typically k + 10..20.
+        float mloc = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { n_valid += __popcll(__ballot(valid[j])); if (!valid[j]) key[j] = 0u; }
-        const int kw = k < n_valid ? k : n_valid;
-        bool exact = false;
-        const unsigned thr = kw > 0 ? wave_kth_key<NV>(key, kw, exact) : 0xFFFFFFFFu;
-        int need = 0;
-        if (kw > 0 && !exact) {
-            int n_gt = 0;
+        for (int j = 0; j < NV; ++j) mloc = (valid[j] && v[j] > mloc) ? v[j] : mloc;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) n_gt += __popcll(__ballot(key[j] > thr));
-            need = kw - n_gt;
-        }
-        int base = 0, tie_seen = 0;
+        for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(mloc, o, 64); mloc = ov > mloc ? ov : mloc; }
+        if (lane == 0) sh_f[w] = mloc;
+        for (int i = tid; i < 1024; i += NT) hist[i] = 0u;
+        if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; wcnt[0] = 0; }
+        __syncthreads();
+        float mx = sh_f[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) mx = sh_f[q] > mx ? sh_f[q] : mx;
+        unsigned bin[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            bool sel;
-            if (exact) {
-                sel = key[j] >= thr;
+            bin[j] = __float_as_uint(__fsub_rn(mx, v[j])) >> 21;        // (max - (-inf) = +inf -> bin 1020; max = -inf -> NaN -> 1022)
+            if (valid[j]) atomicAdd(&hist[bin[j]], 1u);
+        }
+        __syncthreads();
+        const int kf = k < V ? k : V;                                   // every index < V is a candidate (suppressed ones as -inf)
+        if (w == 0) {
+            unsigned c16[16];
+            unsigned sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 h4 = *reinterpret_cast<const uint4*>(&hist[lane * 16 + q * 4]);
+                c16[4 * q] = h4.x; c16[4 * q + 1] = h4.y; c16[4 * q + 2] = h4.z; c16[4 * q + 3] = h4.w;
+                sum += h4.x + h4.y + h4.z + h4.w;
+            }
+            unsigned incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            unsigned run = incl - sum;
+            if (run < (unsigned)kf && incl >= (unsigned)kf) {           // exactly one lane: the running count reaches k inside its 16 bins
+                int bs = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (run < (unsigned)kf) { run += c16[q]; bs = q; }
+                }
+                sh_i[2] = lane * 16 + bs; sh_i[3] = (int)run;
+            }
+        }
+        __syncthreads();
+        const unsigned bstar = (unsigned)sh_i[2];
+        int n_c = sh_i[3];
+        const bool fast = n_c <= NW * 64;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const bool s = valid[j] && bin[j] <= bstar;
+                const unsigned long long b_sel = __ballot(s);
+                if (b_sel) {
+                    int base = 0;
+                    if (lane == (int)__builtin_ctzll(b_sel)) base = atomicAdd(&wcnt[0], __popcll(b_sel));
+                    base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(b_sel));
+                    if (s) ckey[base + lanes_below(b_sel)] = ((unsigned long long)key[j] << 32) | (0xFFFFFFFFu - (unsigned)((w * NV + j) * 64 + lane));
+                }
+            }
+        } else {
+        // ---- fallback (more than NW x 64 values share the bins up to the cut - e.g. a row of equal logits):
+        // phase 1: narrow this wave's keys down to <= 64 that contain its own top-k
+        int n_valid = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) n_valid += __popcll(__ballot(valid[j]));
+        const int kw = k < n_valid ? k : n_valid;
+        unsigned prefix = 1u;                       // key >= 1 <=> valid
+        int cnt_p = n_valid;                        // number of keys >= prefix
+        if (cnt_p > 64) {
+            prefix = 0u;
+            for (unsigned bm = 0x80000000u; bm != 0u; bm >>= 1) {
+                const unsigned pivot = prefix | bm;
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) cnt += __popcll(__ballot(key[j] >= pivot));
+                if (cnt >= kw) {
+                    prefix = pivot; cnt_p = cnt;
+                    if (cnt <= 64) break;
+                }
+            }
+        }
+        // (after all 32 bits the pivot is the wave's k-th key itself; more than 64 keys >= it means equal keys straddle the
+        //  cut - e.g. a wave of suppressed tokens, all -inf: the lowest positions of the equal ones are kept)
+        int need_eq = -1;
+        if (cnt_p > 64) {
+            int n_gt = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) n_gt += __popcll(__ballot(key[j] > prefix));
+            need_eq = kw - n_gt;
+        }
+        if (lane == 0) wpre[w] = (kw == k && kw > 0) ? prefix : 0u;     // a wave with fewer than k keys proves nothing
+        __syncthreads();
+        unsigned T = 0u;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) T = wpre[q] > T ? wpre[q] : T;
+        bool sel[NV];
+        int c_w = 0, tie_seen = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            bool s;
+            if (need_eq < 0) {
+                s = key[j] >= prefix;
             } else {
-                const bool eq = kw > 0 && key[j] == thr;
+                const bool eq = key[j] == prefix;
                 const unsigned long long b_eq = __ballot(eq);
-                sel = (kw > 0 && key[j] > thr) || (eq && tie_seen + lanes_below(b_eq) < need);
+                s = key[j] > prefix || (eq && tie_seen + lanes_below(b_eq) < need_eq);
                 tie_seen += __popcll(b_eq);
             }
-            sel = sel && valid[j];
-            const unsigned long long b_sel = __ballot(sel);
-            if (sel) {
-                const int pos = base + lanes_below(b_sel);
-                if (pos < 64) { wc[w][pos].v = v[j]; wc[w][pos].idx = (w * NV + j) * 64 + lane; }
-            }
-            base += __popcll(b_sel);
+            sel[j] = s && kw > 0 && key[j] >= T;
+            c_w += __popcll(__ballot(sel[j]));
+        }
+        if (lane == 0) wcnt[w] = c_w;
+        __syncthreads();
+        int off = 0;
+        n_c = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { const int cq = wcnt[q]; off += q < w ? cq : 0; n_c += cq; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const unsigned long long b_sel = __ballot(sel[j]);
+            if (sel[j]) ckey[off + lanes_below(b_sel)] = ((unsigned long long)key[j] << 32) | (0xFFFFFFFFu - (unsigned)((w * NV + j) * 64 + lane));
+            off += __popcll(b_sel);
+        }
         }
         if (A.stamps && row == 0 && tid == 0) A.stamps[3] = wall_clock64();
-        if (lane == 0) wcount[w] = base < 64 ? base : 64;
         __syncthreads();
-        // ---- phase 2 (wave 0): the final k out of the 4 lists
-        if (w == 0) {
-            __shared__ Cand fin[64];
-            __shared__ Cand sorted[64];
-            Cand c4[4];
-            unsigned k32[4];
-            int total = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nq = __builtin_amdgcn_readfirstlane(wcount[q]);
-                const bool ok = lane < nq;
-                c4[q] = ok ? wc[q][lane] : Cand{-INFINITY, 0x7fffffff};
-                k32[q] = ok ? okey(c4[q].v) : 0u;
-                total += nq;
-            }
-            const int kf = k < total ? k : total;
-            bool ex2 = false;
-            const unsigned thr2 = kf > 0 ? wave_kth_key<4>(k32, kf, ex2) : 0xFFFFFFFFu;
-            // values equal to the k-th one go to the lowest indices: a second search over the (unique) inverted indices
-            unsigned inv[4];
-            unsigned thr3 = 0u;
-            if (kf > 0 && !ex2) {
-                int n_gt = 0, n_eq = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    n_gt += __popcll(__ballot(k32[q] > thr2));
-                    n_eq += __popcll(__ballot(k32[q] == thr2));
-                    inv[q] = k32[q] == thr2 ? 0xFFFFFFFFu - (unsigned)c4[q].idx : 0u;
-                }
-                if (n_eq > kf - n_gt) { bool ex3; thr3 = wave_kth_key<4>(inv, kf - n_gt, ex3); }
-            }
-            fin[lane] = Cand{-INFINITY, 0x7fffffff};
-            int b2 = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool sel = kf > 0 && k32[q] != 0u && (ex2 ? k32[q] >= thr2 : (k32[q] > thr2 || (k32[q] == thr2 && inv[q] >= thr3)));
-                const unsigned long long bs = __ballot(sel);
-                if (sel) { const int pos = b2 + lanes_below(bs); if (pos < 64) fin[pos] = c4[q]; }
-                b2 += __popcll(bs);
-            }
-            if (A.stamps && row == 0 && tid == 0) A.stamps[4] = wall_clock64();
-            // ---- order by (value desc, index asc): rank = number of candidates ahead of mine (keys are unique), one
-            // scalar broadcast per candidate, then a scatter through LDS puts candidate r on lane r.  (A 21-stage bitonic network
-            // of wave shuffles was measured at 3.2 us against 1.7 us for this: every shuffle is an LDS-crossbar round trip.)
-            Cand c = fin[lane];
-            const unsigned my_hi = okey(c.v), my_lo = 0xFFFFFFFFu - (unsigned)c.idx;     // larger 64-bit key = earlier
-            const unsigned long long my64 = ((unsigned long long)my_hi << 32) | my_lo;
+        // ---- phase 2: rank = number of candidates ahead of mine (keys are unique: value, then lowest index) - at once the exact
+        // top-k selection (rank < k) and the sort.  G consecutive lanes share one candidate and split the comparisons.
+        {
+            int slots = 64;
+            while (slots < n_c) slots <<= 1;
+            int G = NT / slots;
+            G = G > 64 ? 64 : G;
+            const int c = tid / G, part = tid - c * G;
+            const unsigned long long my = c < n_c ? ckey[c] : 0ull;
             int rank = 0;
-#pragma unroll 4
-            for (int j = 0; j < kf; ++j) {
-                const unsigned long long o64 = ((unsigned long long)(unsigned)lane_i32((int)my_hi, j) << 32) | (unsigned)lane_i32((int)my_lo, j);
-                rank += o64 > my64 ? 1 : 0;
+            int j = part;
+            for (; j + 3 * G < n_c; j += 4 * G) {
+                const unsigned long long o0 = ckey[j], o1 = ckey[j + G], o2 = ckey[j + 2 * G], o3 = ckey[j + 3 * G];
+                rank += (o0 > my ? 1 : 0) + (o1 > my ? 1 : 0) + (o2 > my ? 1 : 0) + (o3 > my ? 1 : 0);
             }
-            if (lane < kf) sorted[rank] = c;
-            c = lane < kf ? sorted[lane] : Cand{-INFINITY, 0x7fffffff};
+            for (; j < n_c; j += G) rank += ckey[j] > my ? 1 : 0;
+            for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (part == 0 && c < n_c && rank < kf) sorted[rank] = my;
+        }
+        if (A.stamps && row == 0 && tid == 0) A.stamps[4] = wall_clock64();
+        __syncthreads();
+        if (w == 0) {
+            const unsigned long long mk = lane < kf ? sorted[lane] : 0ull;
+            Cand c;
+            c.v = lane < kf ? okey_inv((unsigned)(mk >> 32)) : -INFINITY;
+            c.idx = lane < kf ? (int)(0xFFFFFFFFu - (unsigned)mk) : 0x7fffffff;
             if (A.stamps && row == 0 && tid == 0) A.stamps[5] = wall_clock64();
             const unsigned long long fin_mask = __ballot(lane < kf && c.v > -INFINITY);
             const int n = __popcll(fin_mask);                                  // finite candidates are a prefix after the sort
@@ -433,10 +488,11 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
                 const int pick_lane = over ? __builtin_ctzll(over) : keep - 1;
                 token = lane_i32(c.idx, pick_lane);
             }
-            if (lane == 0) sh_i[0] = n > 0 ? 0 : 1;      // no finite candidate at all: fall back to the arg-max rule
+            if (lane == 0) { sh_i[0] = n > 0 ? 0 : 1; sh_i[1] = token; }      // no finite candidate at all: fall back to the arg-max rule
         }
         __syncthreads();
         need_argmax = sh_i[0] != 0;
+        token = sh_i[1];
         __syncthreads();
     }
     if (need_argmax) {
@@ -456,9 +512,10 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
         __syncthreads();
         bv = sh_f[0]; bi = sh_i[0];
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) if (sh_f[ww] > bv || (sh_f[ww] == bv && sh_i[ww] < bi)) { bv = sh_f[ww]; bi = sh_i[ww]; }
+        for (int ww = 1; ww < NW; ++ww) if (sh_f[ww] > bv || (sh_f[ww] == bv && sh_i[ww] < bi)) { bv = sh_f[ww]; bi = sh_i[ww]; }
         if (bi == 0x7fffffff) bi = 0;
         token = bi;
+        __syncthreads();
     }
     if (A.stamps && row == 0 && tid == 0) A.stamps[6] = wall_clock64();
     if (tid == 0) {
@@ -469,37 +526,38 @@ __global__ __launch_bounds__(256) void k_sample_w(SampleArgs A) {
         A.out[(int64_t)row * A.out_stride] = token;
         sh_i[0] = token;
     }
-    if (A.emb_table) {      // next pass's input straight from the drawn token (same arithmetic as k_embed_rowsq's f32-table mode)
-        __syncthreads();
+    if (A.emb_table) {      // next pass's input straight from the drawn token (same arithmetic as k_embed_rowsq's f32-table mode:
+        __syncthreads();    // 256 threads x 8 elements, wave sums, then waves 0..3 - threads beyond 256 only keep the barriers)
         const int tok = sh_i[0];
         const int H = A.emb_H;
         float ss = 0.f;
-        for (int c = tid * 8; c < H; c += 2048) {
-            float e[8];
-            const f4s_t a = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c);
-            const f4s_t b = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c + 4);
+        if (tid < 256) {
+            for (int c = tid * 8; c < H; c += 2048) {
+                float e[8];
+                const f4s_t a = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c);
+                const f4s_t b = *reinterpret_cast<const f4s_t*>(A.emb_table + (int64_t)tok * H + c + 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { e[q] = 0.f + a[q]; e[4 + q] = 0.f + b[q]; }
+                for (int q = 0; q < 4; ++q) { e[q] = 0.f + a[q]; e[4 + q] = 0.f + b[q]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ss += e[q] * e[q];
-            const int64_t o = tile_off(row, c, H);
-            *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o) = f4s_t{e[0], e[1], e[2], e[3]};
-            *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o + 4) = f4s_t{e[4], e[5], e[6], e[7]};
-            const f4s_t w0 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c), w1 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c + 4);
-            uint4 pk;
-            pk.x = f32x2_to_bf16x2(w0[0] * e[0], w0[1] * e[1]);
-            pk.y = f32x2_to_bf16x2(w0[2] * e[2], w0[3] * e[3]);
-            pk.z = f32x2_to_bf16x2(w1[0] * e[4], w1[1] * e[5]);
-            pk.w = f32x2_to_bf16x2(w1[2] * e[6], w1[3] * e[7]);
-            *reinterpret_cast<uint4*>(A.emb_a_tiled + o) = pk;
+                for (int q = 0; q < 8; ++q) ss += e[q] * e[q];
+                const int64_t o = tile_off(row, c, H);
+                *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o) = f4s_t{e[0], e[1], e[2], e[3]};
+                *reinterpret_cast<f4s_t*>(A.emb_x_tiled + o + 4) = f4s_t{e[4], e[5], e[6], e[7]};
+                const f4s_t w0 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c), w1 = *reinterpret_cast<const f4s_t*>(A.emb_norm_w + c + 4);
+                uint4 pk;
+                pk.x = f32x2_to_bf16x2(w0[0] * e[0], w0[1] * e[1]);
+                pk.y = f32x2_to_bf16x2(w0[2] * e[2], w0[3] * e[3]);
+                pk.z = f32x2_to_bf16x2(w1[0] * e[4], w1[1] * e[5]);
+                pk.w = f32x2_to_bf16x2(w1[2] * e[6], w1[3] * e[7]);
+                *reinterpret_cast<uint4*>(A.emb_a_tiled + o) = pk;
+            }
+            ss = wave_sum_f32(ss);
         }
-        // block sum in the order k_embed_rowsq uses (wave sums, then waves 0..3)
-        ss = wave_sum_f32(ss);
         __syncthreads();
-        if (lane == 0) sh_f[w] = ss;
+        if (lane == 0 && w < 4) sh_f[w] = ss;
         __syncthreads();
         const float tot = ((sh_f[0] + sh_f[1]) + sh_f[2]) + sh_f[3];
-        for (int j = tid; j < A.emb_rowsq_n; j += 256) A.emb_rowsq[(int64_t)row * A.emb_rowsq_n + j] = j == 0 ? tot : 0.f;
+        for (int j = tid; j < A.emb_rowsq_n; j += NT) A.emb_rowsq[(int64_t)row * A.emb_rowsq_n + j] = j == 0 ? tot : 0.f;
     }
 }
 
@@ -512,9 +570,9 @@ int launch_sample(rt_ctx* ctx, const SampleArgs& a) {
     if (a.V > 16384) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "vocabulary %d too large for the sampler", a.V);
     if (a.emb_table && (a.V > 4096 || a.emb_H % 8 || !a.emb_norm_w || !a.emb_rowsq || a.emb_rowsq_n < 1 || !a.emb_x_tiled || !a.emb_a_tiled))
         return rt_fail(ctx, RT_ERR_INVALID, "sample: fused embedding needs V <= 4096, H %% 8 == 0 and all its buffers");
-    if (a.V <= 1024) hipLaunchKernelGGL(k_sample_w<4>, dim3(a.M), dim3(256), 0, ctx->stream, a);
-    else if (a.V <= 2048) hipLaunchKernelGGL(k_sample_w<8>, dim3(a.M), dim3(256), 0, ctx->stream, a);
-    else if (a.V <= 4096) hipLaunchKernelGGL(k_sample_w<16>, dim3(a.M), dim3(256), 0, ctx->stream, a);
+    if (a.V <= 1024) hipLaunchKernelGGL((k_sample_w<4, 4>), dim3(a.M), dim3(256), 0, ctx->stream, a);
+    else if (a.V <= 2048) hipLaunchKernelGGL((k_sample_w<4, 8>), dim3(a.M), dim3(512), 0, ctx->stream, a);
+    else if (a.V <= 4096) hipLaunchKernelGGL((k_sample_w<4, 16>), dim3(a.M), dim3(1024), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_sample, dim3(a.M), dim3(256), a.V * sizeof(float), ctx->stream, a);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;

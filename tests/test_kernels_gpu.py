@@ -181,14 +181,26 @@ def test_attention_matches_fp32(ctx, d, heads, kvh, window):
         assert float((out[r].float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
 
 
-def test_sampler_matches_oracle_draw_for_draw(ctx):
+@pytest.mark.parametrize("V,sup_from", [(3072, 2048), (2048, 2048), (2048, 1500), (1000, 640), (4096, 2730), (700, 690), (6000, 5000)])
+def test_sampler_matches_oracle_draw_for_draw(ctx, V, sup_from):
+    """Every sampler instantiation (4 / 8 / 16 waves for V <= 1024 / 2048 / 4096, the LDS kernel above) against
+    oracle/sampling.py, draw for draw.  Rows built to hit the selection's corner cases: ties at the top, all values equal,
+    logits quantised to 1/4 (ties AT the top-k cut, to be resolved by lowest index), fewer finite values than k (the rest
+    suppressed), one finite value, and a row whose top values all sit in the last wave."""
     from oracle.sampling import SamplingParams, draw, uniform
     from rho_tts_amd._native_model import RtSampling
-    M, V = 24, 3072
-    g = torch.Generator().manual_seed(31)
+    M = 24
+    allow = min(V - 1, sup_from + 102)
+    g = torch.Generator().manual_seed(31 + V)
     logits = (torch.randn(M, V, generator=g) * 2.0)
     logits[3, 100] = logits[3, 200] = float(logits[3].max()) + 1.0          # a tie at the top
     logits[4, :] = 0.5                                                       # all equal
+    logits[5] = torch.round(logits[5] * 4) / 4                               # many ties, some across the top-k cut
+    logits[6] = torch.round(logits[6])
+    logits[7, : sup_from - 7] = float("-inf")                                # 7 finite values (+ the allowed token): fewer than k
+    logits[8, :] = float("-inf"); logits[8, 17] = 0.25                       # one finite value
+    logits[9, sup_from - 40: sup_from] += 9.0                                # the whole top-k in the last waves
+    logits[10, :64] += 9.0; logits[10, :64] = torch.round(logits[10, :64])   # the whole top-k in ONE wave, with ties
     seen_h = torch.rand(M, V, generator=g) < 0.05
     cases = [SamplingParams(False), SamplingParams(True, 0.9, 50, 1.0, 1.0), SamplingParams(True, 1.3, 64, 0.8, 1.05),
              SamplingParams(True, 0.7, 1, 1.0, 1.0), SamplingParams(True, 1.0, 5, 0.3, 1.2)]
@@ -198,11 +210,11 @@ def test_sampler_matches_oracle_draw_for_draw(ctx):
         rs = RtSampling(int(sp.do_sample), sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty)
         lg = logits.cuda()
         torch.cuda.synchronize()
-        ctx.check(ctx.lib.rt_debug_sample(ctx.handle, lg.data_ptr(), M, V, C.byref(rs), 789 + (5 << 32), 7, 3, 2048, 2150,
+        ctx.check(ctx.lib.rt_debug_sample(ctx.handle, lg.data_ptr(), M, V, C.byref(rs), 789 + (5 << 32), 7, 3, sup_from, allow,
                                           seen.data_ptr(), out.data_ptr()), "rt_debug_sample")
         sup = np.zeros(V, bool)
-        sup[2048:] = True
-        sup[2150] = False
+        sup[sup_from:] = True
+        sup[allow] = False
         want = [draw(logits[r].numpy(), sp, uniform(789 + (5 << 32), r, 7, 3), sup, seen_h[r].numpy()) for r in range(M)]
         got = out.cpu().tolist()
         # a draw can legitimately differ only when u falls within float rounding of a CDF boundary: allow at most one
