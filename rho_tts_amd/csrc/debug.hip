@@ -239,6 +239,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 1800) { g_conv_tall = skinny_variant - 1800; return RT_OK; }           // 1800/1801: 128- / 256-row tiles for the narrow-channel k>1 convs
     if (skinny_variant >= 1700) { g_handover_every = std::max(1, skinny_variant - 1700); return RT_OK; }  // 17nn: queued items take over finished rows every nn frames
     if (skinny_variant >= 1600) { g_col_split4 = skinny_variant - 1600; return RT_OK; }           // 1600/1601: quarter-tile split of N <= 1024 decode GEMMs off/on
     if (skinny_variant >= 1500) { g_attn_mfma = skinny_variant - 1500; return RT_OK; }            // 1500/1501: MFMA shared-prefix decode attention off/on

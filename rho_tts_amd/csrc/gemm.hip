@@ -514,10 +514,16 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tiled(TiledArgs g) {
 // can see - 128 + (taps-1)*dilation of them - ONCE per 32-channel chunk, and the taps are fragment reads at shifted LDS rows:
 // one barrier per `taps` MFMA steps, the next chunk's window in flight during all of them.
 // Requires rows_in == rows_out, tap_offset = -(taps-1)*tap_stride, Cin % 32 == 0, (taps-1)*tap_stride <= 64, split_k = 1.
-constexpr int WIN_ROWS = BM + 64;
+// The workgroup tile is (WGM*MT*32) rows: 128 by default; 256 (MT doubled) for the 96- and 192-channel stages, whose four
+// waves all need the SAME weight fragments (the waves split the rows, not the 96 columns) - with 3 workgroups per CU the
+// per-CU vector L1 (64 B/clk) then moves as many weight bytes per tap as the SIMDs spend cycles on its MFMAs; twice the
+// rows per weight fragment halves that.
 template <int WGM, int WGN, int MT, int NTT>
-__global__ __launch_bounds__(256, 3) void k_conv_win(TiledArgs g) {
-    static_assert(WGM * WGN == 4 && WGM * MT * 32 == BM, "4 waves, 128 rows");
+__global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win(TiledArgs g) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int BMT = WGM * MT * 32;
+    constexpr int WIN_ROWS = BMT + 64;
+    constexpr int NP = (WIN_ROWS * 4 + 255) / 256;        // 16-B window pieces per thread and plane
     constexpr int BNT = WGN * NTT * 32;
     constexpr int PLANE = WIN_ROWS * 64;                  // bytes per plane and stage
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * PLANE];
@@ -532,28 +538,28 @@ __global__ __launch_bounds__(256, 3) void k_conv_win(TiledArgs g) {
         const int64_t j = L >> 3;
         ct = (int)(j % gridDim.y);
         rt = (j / gridDim.y) * 8 + xcd;
-        if (rt * BM >= g.a.M) return;
+        if (rt * BMT >= g.a.M) return;
     }
-    const int64_t m0 = rt * BM;
+    const int64_t m0 = rt * BMT;
     const int n0 = ct * BNT;
     const int taps = g.a.taps, stride = g.a.tap_stride, Cin = g.a.Cin;
-    const int halo = (taps - 1) * stride, WR = BM + halo, n_cc = Cin >> 5;
+    const int halo = (taps - 1) * stride, WR = BMT + halo, n_cc = Cin >> 5;
     const bf16_t* __restrict__ hi = reinterpret_cast<const bf16_t*>(g.a.ptr);
     const bf16_t* __restrict__ lo = reinterpret_cast<const bf16_t*>(g.a.ptr_lo);
 
     // ---- window staging: piece p = tid + 256 i -> (window row p >> 2, 16-B slot p & 3); global row = m0 - halo + row
-    int64_t p_off[3];
-    bool p_ok[3];
+    int64_t p_off[NP];
+    bool p_ok[NP];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int p = tid + i * 256, row = p >> 2, slot = p & 3;
         const int64_t gr = m0 - halo + row;
         p_ok[i] = row < WR && gr >= 0 && gr < g.a.M;
         p_off[i] = gr * Cin + slot * 8;
     }
-    auto load_win = [&](int cc, s8_t (&a)[3], s8_t (&l)[3]) {
+    auto load_win = [&](int cc, s8_t (&a)[NP], s8_t (&l)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NP; ++i) {
             if (p_ok[i]) {
                 a[i] = *reinterpret_cast<const s8_t*>(hi + p_off[i] + cc * 32);
                 l[i] = *reinterpret_cast<const s8_t*>(lo + p_off[i] + cc * 32);
@@ -563,9 +569,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_win(TiledArgs g) {
             }
         }
     };
-    auto store_win = [&](int buf, const s8_t (&a)[3], const s8_t (&l)[3]) {
+    auto store_win = [&](int buf, const s8_t (&a)[NP], const s8_t (&l)[NP]) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int p = tid + i * 256;
             if ((p >> 2) < WIN_ROWS) {
                 *reinterpret_cast<s8_t*>(lds + buf * 2 * PLANE + lds_a_off(p >> 2, p & 3)) = a[i];
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_win(TiledArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    s8_t ra[3], rl[3], rb[NTT][2], rb_next[NTT][2];
+    s8_t ra[NP], rl[NP], rb[NTT][2], rb_next[NTT][2];
     load_win(0, ra, rl);
     load_b(0, 0, rb);
     store_win(0, ra, rl);
@@ -697,6 +703,7 @@ int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one laun
 int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
 int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
 int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its own LDS-window kernel
+int g_conv_tall = 1;            // 1: 256-row tiles for the k>1 convs of the 96- / 192-channel stages
 int g_conv_win = 1;             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
@@ -769,10 +776,15 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     int per = (g.KT + e.split_k - 1) / e.split_k;
     per = (per + 1) / 2 * 2;
     g.kt_per_split = per;
-    const int64_t my = (a.M + BM - 1) / BM;
-    if (my > 0x7fffffff) return rt_fail(ctx, RT_ERR_LENGTH, "gemm: length %lld rows too large", (long long)a.M);
     // 96-wide workgroup tiles when N is a multiple of 96 but not of 128 (the decoder's 96- and 192-channel stages)
     const bool narrow = g_tile96 && e.split_k == 1 && w.N % 96 == 0 && w.N % 128 != 0;
+    // codec decoder k>1 convs on operand planes: input window in LDS (k_conv_win)
+    const bool conv_win = g_conv_win && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 && a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out &&
+        a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 && e.split_k == 1 && a.M % a.rows_out == 0;
+    const bool tall = conv_win && narrow && (g_conv_tall == 2 || (g_conv_tall == 1 && a.M >= 256 * 1024));   // 256-row tiles (see k_conv_win; 2 = forced, tests)
+    const int bm = tall ? 256 : BM;
+    const int64_t my = (a.M + bm - 1) / bm;
+    if (my > 0x7fffffff) return rt_fail(ctx, RT_ERR_LENGTH, "gemm: length %lld rows too large", (long long)a.M);
     const int bn = narrow ? 96 : BN;
     const int ny = (w.N + bn - 1) / bn;
     g.xcd_order = (g_xcd_order && e.split_k == 1 && ny > 1 && my >= 64) ? 1 : 0;
@@ -781,10 +793,9 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || (e.act2 != ACT_ELU && (!e.snake2_a || !e.snake2_ib)))) ||
         ((e.out_hi || e.out2_hi) && e.split_k > 1))
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");
-    // codec decoder k>1 convs on operand planes: input window in LDS (k_conv_win)
-    if (g_conv_win && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 && a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out &&
-        a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 && e.split_k == 1 && a.M % a.rows_out == 0) {
-        if (narrow) hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);
+    if (conv_win) {
+        if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3>), grid, dim3(256), 0, ctx->stream, g);
+        else if (narrow) hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((k_conv_win<2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);
         RT_HIP(ctx, hipGetLastError());
         return RT_OK;

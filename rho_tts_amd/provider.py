@@ -464,6 +464,54 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
                 watcher.join(timeout=1.0)
         return wavs[0] if single else wavs
 
+    def stream(self, text: str, cancellation_token: Optional[CancellationToken] = None, speed: float = 1.0,
+               pitch_semitones: float = 0.0):
+        """``BaseTTS.stream`` (base_tts.py:1132-1190): one result per segment, no crossfade, failed segments skipped - with the
+        same audio per segment, produced in two calls instead of one per segment: the FIRST segment alone (time to first
+        audio = one short decode), then ALL the others in one batched call while the caller is busy with the first.
+        Every segment keeps RNG stream 0, which is what a one-segment ``_generate_audio`` call uses, so the results equal the
+        sequential loop's."""
+        from .api import GenerationResult
+        token = cancellation_token or CancellationToken()
+        segments = self._split_text_into_segments(self._apply_phonetic_mapping(text), self._compute_max_chars())
+
+        def finish(raw: torch.Tensor):
+            audio = self._post_process_audio(raw)
+            audio = self._apply_fades(self._remove_dc_offset(self._trim_silence(audio, True, True)), True, True)
+            if speed != 1.0 or pitch_semitones != 0.0:
+                audio = self._apply_speed_pitch(audio, speed, pitch_semitones)
+            n_samples = audio.shape[-1] if audio.dim() == 2 else audio.numel()
+            return GenerationResult(audio=audio, sample_rate=self.sample_rate, duration_sec=n_samples / self.sample_rate,
+                                    segments_count=1, format="wav")
+
+        for first, group in ((0, segments[:1]), (1, segments[1:])):
+            if not group or token.is_cancelled():
+                continue
+            self._set_seeds()
+            try:
+                raws: List[Optional[torch.Tensor]] = list(self._generate_audio(list(group), item_ids=[0] * len(group), cancellation_token=token))
+            except CancelledException:
+                return
+            except Exception as first_error:  # noqa: BLE001  (the batch failed: let every segment fail or pass on its own)
+                raws = []
+                for seg in group:
+                    try:
+                        raws.append(self._generate_audio(seg, cancellation_token=token))
+                    except CancelledException:
+                        return
+                    except Exception as e:  # noqa: BLE001
+                        logger.warning(f"Segment {first + len(raws) + 1} failed: {e} (batched call: {first_error})")
+                        raws.append(None)
+            for k, raw in enumerate(raws):
+                if token.is_cancelled():
+                    return
+                if raw is None:
+                    continue
+                try:
+                    yield finish(raw)
+                except Exception as e:  # noqa: BLE001
+                    logger.warning(f"Segment {first + k + 1} failed: {e}")
+
     @property
     def sample_rate(self) -> int:
         return 24000 if self._engine is None else self._engine.cfg.sample_rate

@@ -126,8 +126,9 @@ def test_causal_dilated_conv_on_operand_planes(ctx, C_in, C_out, dil, T, B):
     ref = torch.nn.functional.conv1d(torch.nn.functional.pad(x.transpose(1, 2), (6 * dil, 0)), w.float(), dilation=dil).transpose(1, 2)
     outs = []
     try:
-        for code in (1201, 1200):
-            ctx.lib.rt_debug_tune(code, 0)
+        for codes in ((1201, 1800), (1200, 1800), (1201, 1802)):      # window kernel, per-tap kernel, window kernel with 256-row tiles (forced)
+            for code in codes:
+                ctx.lib.rt_debug_tune(code, 0)
             out = torch.empty(B * T, C_out, device="cuda")
             torch.cuda.synchronize()
             ctx.check(ctx.lib.rt_debug_gemm(ctx.handle, planes.data_ptr(), 3, B * T, C_in, 7, dil, -6 * dil, T, T, wm.data_ptr(), C_out, None, 0,
@@ -135,9 +136,11 @@ def test_causal_dilated_conv_on_operand_planes(ctx, C_in, C_out, dil, T, B):
             outs.append(out.view(B, T, C_out).cpu())
     finally:
         ctx.lib.rt_debug_tune(1201, 0)
+        ctx.lib.rt_debug_tune(1801, 0)
     for out in outs:
         assert float((out - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
     assert float((outs[0] - outs[1]).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(outs[0], outs[2])                                # same products, same order: the tile height changes nothing
 
 
 @pytest.mark.parametrize("C_in,C_out,r,T,B", [(32, 16, 3, 20, 2), (64, 32, 8, 45, 3), (96, 48, 2, 7, 1)])

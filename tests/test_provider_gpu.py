@@ -153,6 +153,15 @@ def test_stream_cancel_and_config_errors(tiny_provider):
     finally:
         p.max_chars_per_segment, p._max_chars_explicit, p.force_sentence_split = 1000, False, False
     assert len(parts) == 3 and all(x.segments_count == 1 and x.audio.numel() > 0 for x in parts)
+    # the provider streams in two calls (first segment alone, the others batched): same audio as the per-segment loop of BaseTTS.stream
+    p.max_chars_per_segment, p._max_chars_explicit, p.force_sentence_split = 30, True, True
+    try:
+        ref_parts = list(api.BaseTTS.stream(p, "First sentence here. Second sentence there. Third one."))
+    finally:
+        p.max_chars_per_segment, p._max_chars_explicit, p.force_sentence_split = 1000, False, False
+    assert len(ref_parts) == 3
+    for a, b in zip(parts, ref_parts):
+        assert torch.equal(a.audio.cpu(), b.audio.cpu())
     tok = api.CancellationToken()
     tok.cancel()
     assert p.generate("Anything", cancellation_token=tok) is None
