@@ -70,6 +70,7 @@ __global__ void k_fill_i32(int32_t* p, int n, int v, int step_every, int step) {
 }  // namespace
 
 struct rt_model {
+    bool prefix_tiles_valid = false;   // kt_prefix / vt_prefix hold the current voice prefix (attention_mfma.hip)
     int64_t last_frames_run = 0, last_rows = 0, last_kept = 0, last_swaps = 0;   // rt_generate_stats
     rt_ctx* ctx = nullptr;
     rt_model_config cfg{};
@@ -848,7 +849,7 @@ static int set_voice_impl(rt_model* m, int32_t n_rows, const int32_t* h_text_ids
     bf16_t* hn = nullptr;
     RT_TRY(pool_arr(m, (size_t)n_rows * H, &hn));
     RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr));
-    if (c.talker.head_dim == 128) RT_TRY(launch_transpose_prefix_v(ctx, m->talker.kv, n_rows));
+    m->prefix_tiles_valid = false;     // (fragment-tiled prefix copies are only built when the matrix-core attention is switched on: rt_generate)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->prefix_len = n_rows;
     pool_release_all(m);
@@ -1045,7 +1046,7 @@ static int voice_blob(rt_model* m, void* d_blob, int64_t bytes, int to_blob, int
     hipLaunchKernelGGL(k_kv_blob, dim3(d.layers * d.kv_heads, 2), dim3(256), 0, ctx->stream, kv.k, kv.v, (int64_t)kv.layer_stride(), d.layers,
                        d.kv_heads, kv.max_pos, d.head_dim, m->prefix_slot(), prefix_len, (bf16_t*)d_blob, to_blob);
     RT_HIP(ctx, hipGetLastError());
-    if (!to_blob && d.head_dim == 128) RT_TRY(launch_transpose_prefix_v(ctx, kv, prefix_len));
+    if (!to_blob) m->prefix_tiles_valid = false;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!to_blob) m->prefix_len = prefix_len;
     return RT_OK;
@@ -1111,6 +1112,10 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // ---- the voice prefix KV stays in its own slot: every sequence reads cache rows [0, Lp) from there (KvCache::prefix_slot)
     m->talker.kv.prefix_slot = m->prefix_slot();
     m->talker.kv.prefix_len = Lp;
+    if (g_attn_mfma && c.talker.head_dim == 128 && !m->prefix_tiles_valid) {
+        RT_TRY(launch_transpose_prefix_v(ctx, m->talker.kv, Lp));
+        m->prefix_tiles_valid = true;
+    }
     // ---- suffix rows: [text tokens + tts_eos] x codec_pad, then (tts_pad, codec_bos).  Row 0 of the id / embedding buffers
     // is the projected tts_pad that every decode step adds to its input; the suffix rows of the items being prefilled follow.
     const int S_cap = queued ? B * max_suffix : n_suffix;
@@ -1411,7 +1416,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
                 mix((uint64_t)(uintptr_t)p);
                 mix(ln.b0); mix(ln.n);
             }
-        mix(B); mix(col); mix(n_lanes); mix(A->ignore_eos); mix(A->min_frames);
+        mix(B); mix(col); mix(n_lanes); mix(A->ignore_eos); mix(A->min_frames); mix(g_attn_mfma); mix(g_col_split); mix(g_col_split4); mix(g_col_rows64); mix(g_fuse_sample_embed);
         // the attention nodes carry the voice prefix (slot, length) by value: a voice of another length must not replay the
         // old graphs.  The prefix KV *content* is read through pointers, so re-setting a voice of the same length keeps them.
         mix((uint64_t)Lp); mix((uint64_t)(int64_t)m->talker.kv.prefix_slot);

@@ -137,7 +137,7 @@ class Engine:
             raise ValueError("no voice set: reference audio (Base models) or a built-in speaker (CustomVoice) is required")
         ids = [self.tokenizer.encode(t) for t in texts]
         frames = list(max_frames) if max_frames is not None else [self.frames_for(t, len(i)) for t, i in zip(texts, ids)]
-        limit = self.model.max_positions - self.model.prefix_len() - 4
+        limit = self.model.max_positions - self.model.prefix_len() - 12     # (queued items step a few positions past their last frame)
         for i, f in zip(ids, frames):
             if len(i) + 2 + f > limit:
                 raise RuntimeError(f"length: text of {len(i)} tokens + {f} frames exceeds the {limit} free KV rows")

@@ -26,7 +26,8 @@ TTSFactory._default_providers_registered = True              # never let default
 from rho_tts_amd.provider import MI355XQwenTTS, PROVIDER_NAME, register
 assert register() == PROVIDER_NAME and TTSFactory._providers[PROVIDER_NAME] is MI355XQwenTTS
 assert issubclass(MI355XQwenTTS, B.BaseTTS)
-assert MI355XQwenTTS.generate is B.BaseTTS.generate and MI355XQwenTTS.stream is B.BaseTTS.stream     # inherited, not re-implemented
+assert MI355XQwenTTS.generate is B.BaseTTS.generate                                                    # inherited, not re-implemented
+assert MI355XQwenTTS.stream is not B.BaseTTS.stream        # same results per segment, two batched calls (tests/test_provider_gpu.py)
 assert MI355XQwenTTS._run_pipeline is not B.BaseTTS._run_pipeline                                     # the batching seam
 assert api.CancelledException is rho_tts.CancelledException and api.GenerationResult is rho_tts.GenerationResult
 try:
