@@ -96,7 +96,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # (RHO_TTS_AMD_FORCE_DIST=1: take the collective path with ONE rank too - how the RCCL call sites are exercised on a one-GPU box)
+    if world > 1 or os.environ.get("RHO_TTS_AMD_FORCE_DIST", "") not in ("", "0"):
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         n_dev = torch.cuda.device_count()
@@ -113,7 +114,7 @@ def main():
     from rho_tts_amd import _native, config
     from rho_tts_amd.engine import Engine
     from rho_tts_amd.voice import synthetic_reference_clip
-    from rho_tts_amd.dist import broadcast_voice, gather_waveforms, padding_efficiency, plan_corpus, unshard
+    from rho_tts_amd.dist import broadcast_voice, gather_waveforms, padding_efficiency, plan_corpus, unshard, waveforms_to_host
 
     cfg = config.PRESETS[args.model]()
     log(f"rank {rank}/{world}: building {cfg.name} engine (synthetic weights) ...")
@@ -170,7 +171,7 @@ def main():
             if corpus is not None and rank == 0:
                 host = unshard(host, shards, len(corpus))
         else:
-            host = [o.cpu() for o in outs]
+            host = waveforms_to_host(outs)
         return audio_s, host
 
     log(f"engine ready: {eng.model.weight_bytes() / 1e9:.2f} GB of weights; warmup x{args.warmup}")

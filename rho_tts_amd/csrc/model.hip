@@ -3,6 +3,7 @@
 // attention.hip and sampling.hip.  Stands behind the third-party model object the reference drives at
 // providers/qwen.py:160-165 (load), :247-258 (generate_custom_voice / generate_voice_clone).
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 
@@ -72,6 +73,7 @@ __global__ void k_fill_i32(int32_t* p, int n, int v, int step_every, int step) {
 struct rt_model {
     bool prefix_tiles_valid = false;   // kt_prefix / vt_prefix hold the current voice prefix (attention_mfma.hip)
     int64_t last_frames_run = 0, last_rows = 0, last_kept = 0, last_swaps = 0;   // rt_generate_stats
+    double last_launch_host_us = 0.0;  // host time spent inside the frame-part launches of the last rt_generate
     rt_ctx* ctx = nullptr;
     rt_model_config cfg{};
     std::vector<Slot> slots;
@@ -1467,6 +1469,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     for (int b = 0; b < B; ++b) { row_item[b] = b; item_row[b] = b; }
     int next_item = B, n_finished = 0;
     int64_t n_swaps = 0;
+    double launch_host_us = 0.0;
     int frames_run = 0;
     bool cancelled = false;
     // End-of-sequence is decided on the device (the sampler writes one flag per row and frame); the host only needs the
@@ -1543,8 +1546,10 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             Lane& ln = lanes[l];
             if (ln.done || t >= lane_frames[l]) continue;
             ctx->stream = ln.stream;
+            const auto h0 = std::chrono::steady_clock::now();
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l], ln.stream));
             else RT_TRY(enqueue_a(ln));
+            launch_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
             if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         }
         ctx->stream = main_stream;
@@ -1571,8 +1576,10 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             Lane& ln = lanes[l];
             if (ln.done || t + 1 >= lane_frames[l]) continue;
             ctx->stream = ln.stream;
+            const auto h0 = std::chrono::steady_clock::now();
             if (use_graph) RT_HIP(ctx, hipGraphLaunch(m->graphs[2 * l + 1], ln.stream));
             else RT_TRY(enqueue_b(ln));
+            launch_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
             if (g_sync_parts) RT_HIP(ctx, hipStreamSynchronize(ln.stream));
         }
         ctx->stream = main_stream;
@@ -1610,7 +1617,8 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
             for (int q = 0; q < G; ++q) A->h_codes[(off + t) * G + q] = codes_host[((size_t)(start[it] + t) * B + r) * G + q];
         off += A->h_max_frames[it];
     }
-    m->last_frames_run = frames_run; m->last_rows = B; m->last_kept = kept; m->last_swaps = n_swaps;
+    m->last_frames_run = frames_run; m->last_rows = B; m->last_kept = kept; m->last_swaps = n_swaps; m->last_launch_host_us = launch_host_us;
+    if (getenv("RHO_TTS_AMD_TRACE_HOST")) fprintf(stderr, "rt_generate: %d frames, host time inside frame launches %.1f us (%.1f us per frame)\n", frames_run, launch_host_us, launch_host_us / std::max(1, frames_run));
     return RT_OK;
 }
 

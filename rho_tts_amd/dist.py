@@ -77,6 +77,43 @@ def broadcast_voice(engine, dist, src: int = 0, comm_device=None) -> None:
             engine.voice = VoiceConditioning("(imported)", None, None, [], None)
 
 
+_PINNED: dict = {}
+
+
+def _to_host(t: torch.Tensor) -> torch.Tensor:
+    """Device -> host through a cached PINNED staging buffer (a pageable ``.cpu()`` runs at a third of the PCIe rate); the
+    result is a fresh pageable tensor, so the staging buffer can be reused by the next call."""
+    if not t.is_cuda or t.numel() == 0:
+        return t.cpu()
+    key = (t.dtype, t.device.index)
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < t.numel():
+        buf = torch.empty(max(t.numel(), 1 << 20), dtype=t.dtype, pin_memory=True)
+        _PINNED[key] = buf
+    view = buf[: t.numel()]
+    view.copy_(t.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return view.clone().reshape(t.shape)
+
+
+def waveforms_to_host(wavs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """One packed device buffer, one pinned copy, then views per waveform (instead of one pageable copy per item)."""
+    live = [w for w in wavs if w is not None and w.numel()]
+    if not live or not live[0].is_cuda:
+        return [None if w is None else w.cpu() for w in wavs]
+    host = _to_host(torch.cat([w.reshape(-1) for w in live]))
+    out, o = [], 0
+    for w in wavs:
+        if w is None:
+            out.append(None)
+        elif w.numel() == 0:
+            out.append(torch.zeros(0))
+        else:
+            out.append(host[o: o + w.numel()])
+            o += w.numel()
+    return out
+
+
 def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=None) -> Optional[List[List[torch.Tensor]]]:
     """Variable-length gather: returns on ``dst`` a list (per rank) of lists of CPU float32 waveforms, else None.
     One length exchange plus one padded payload gather; ``None`` items travel as length -1."""
@@ -104,7 +141,7 @@ def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=No
         dist.gather(payload, gather_list=bufs, dst=dst)
         out: List[List[torch.Tensor]] = []
         for r in range(world):
-            host = bufs[r][: totals[r]].cpu()
+            host = _to_host(bufs[r][: totals[r]])
             items, o = [], 0
             for n in all_lens[r].tolist()[: int(counts[r])]:
                 if n < 0:

@@ -247,3 +247,24 @@ def test_eos_checked_every_k_frames_equals_every_frame():
         nm.lib.rt_debug_tune(1408, 0)
         nm.close()
         ctx.close()
+
+
+def test_bench_collective_path_on_rccl_with_one_rank(tmp_path):
+    """bench.py's multi-GPU step - RCCL broadcast of the voice-prefix KV blob, length all-gather, padded gather of the
+    waveforms, MAX all-reduce of the step time - launched exactly as the driver launches it (torch.distributed.run, backend
+    nccl = RCCL), with the one rank a one-GPU box has.  The N > 1 logic is covered by the world-size-2 gloo tests; this one
+    proves every collective call is accepted by the RCCL backend on the hardware."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RHO_TTS_AMD_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    for corpus in ([], ["--corpus", "24"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--model",
+                            "small" if corpus else "tiny",                      # (the corpus' 24-word texts need more KV rows than `tiny` has)
+                            "--batch", "4", "--ref-seconds", "1", "--no-cpu-baseline", "--no-roofline"] + corpus,
+                           cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == ("strong" if corpus else "weak")
