@@ -285,7 +285,8 @@ RT_API int rt_profile_read(rt_model* m, int64_t* n_launches, double* total_ms, d
  * when a_is_f32 = 2; a_is_f32 = 3: d_a holds the bf16 hi plane followed by the bf16 lo plane, as a producing epilogue
  * writes them): output row (b, t) reads input
  * rows t + tap_offset + tap*tap_stride, zero outside [0, rows_in).  mode 0: LDS-tiled kernel (split_k slabs are
- * summed on return), mode 1: weight-streaming skinny kernel (plain A only, M <= 64). */
+ * summed on return), mode 1: weight-streaming skinny kernel (plain A only, M <= 64), mode 2: the prompt-prefill kernel
+ * (k_gemm_mid: plain bf16 A, 65..1024 rows, K a multiple of 64, final sums from 64 x 64 tiles over the whole K). */
 RT_API int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int32_t cin, int32_t taps, int32_t tap_stride,
                          int32_t tap_offset, int32_t rows_out, int32_t rows_in, const void* d_w_bf16, int32_t N,
                          const float* d_bias, int32_t act, float* d_out, int32_t mode, int32_t split_k);
@@ -328,6 +329,7 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame) |
  *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores | 1600/1601 quarter-tile split off/on |
  *   17nn queued items (rt_generate with n_items > max_batch) take over finished rows every nn frames (default 4) |
+ *   1900/1901/1902/1903 prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid (automatic, 64 x 64, 128 x 128 tiles) |
  *   1800/1801/1802 narrow-channel (96 / 192) k>1 convs on 128-row tiles / 256-row tiles for long inputs / 256-row tiles always
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */

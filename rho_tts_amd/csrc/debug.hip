@@ -61,7 +61,14 @@ int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int
     PackedW pw;
     int rc = launch_pack_weight(ctx, (const bf16_t*)d_w_bf16, N, K, packed, &pw);
     if (!rc) {
-        if (mode == 1) {
+        if (mode == 2) {             // the prompt-prefill kernel (k_gemm_mid): plain bf16 A, 65..1024 rows, K a multiple of 64
+            if (a_is_f32 || taps != 1 || !gemm_mid_ok((int)M, pw)) rc = rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm: mid mode needs a plain bf16 A, 65..1024 rows, K %% 64 == 0");
+            else {
+                if (hipMalloc((void**)&slabs, (size_t)M * N * 4) != hipSuccess) rc = RT_ERR_OOM;
+                if (!rc) rc = launch_gemm_mid(ctx, (const bf16_t*)d_a, (int)M, pw, slabs, N);
+                if (!rc) rc = launch_reduce_slabs(ctx, slabs, 1, M, N, d_bias, act, d_out, nullptr);
+            }
+        } else if (mode == 1) {
             if (a_is_f32 || taps != 1) rc = rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm: skinny mode needs a plain bf16 A");
             else {
                 if (split_k < 1) split_k = skinny_pick_split((int)M, N, K, ctx->n_cu);
@@ -239,6 +246,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 1900) { g_prefill_mid = skinny_variant - 1900; return RT_OK; }         // 1900/1901: prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid
     if (skinny_variant >= 1800) { g_conv_tall = skinny_variant - 1800; return RT_OK; }           // 1800/1801: 128- / 256-row tiles for the narrow-channel k>1 convs
     if (skinny_variant >= 1700) { g_handover_every = std::max(1, skinny_variant - 1700); return RT_OK; }  // 17nn: queued items take over finished rows every nn frames
     if (skinny_variant >= 1600) { g_col_split4 = skinny_variant - 1600; return RT_OK; }           // 1600/1601: quarter-tile split of N <= 1024 decode GEMMs off/on

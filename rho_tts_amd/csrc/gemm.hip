@@ -508,6 +508,149 @@ __global__ __launch_bounds__(256, 3) void k_gemm_tiled(TiledArgs g) {
     tile_epilogue<MT, NTT>(g, acc, m0, n0, wm, wn, r, h);
 }
 
+// ----------------------------------------------------------------------------------------- mid-M (prompt prefill)
+// out[M][N] (f32) = A[M][K] (bf16, row-major) W^T for a few hundred rows (the voice-prefix and suffix prefills: 400-500 rows).
+// The 128 x 128 kernel above only fills the chip for such M by splitting K eight ways, and then moves more float32 partial
+// slabs (S x M x N x 4 B written, then re-read by the consumer) than weights.  Here a workgroup owns a 64 x 64 tile for the
+// WHOLE K - M = 460, N = 2048 already gives 256 workgroups - and writes final sums.  Both operands go through LDS (the packed
+// weight fragments verbatim, so no wave re-reads another's through the vector L1), 64 deep per stage, two stages of loads in
+// flight in registers behind the one being multiplied.  Per-CU bound: (64 + 64) x K x 2 B through a 64 B/clk L1.
+constexpr int MID_BK = 64;
+struct MidArgs {
+    const bf16_t* A;
+    const bf16_t* Wp;
+    float* out;
+    int M, N, K, NT, KT;
+    int64_t ldc;
+};
+// WM x WN 32 x 32 MFMA tiles per wave, 2 x 2 waves: the workgroup tile is (64 WM) x (64 WN).  Cache-to-CU traffic is
+// M N K 2 B x (1 / BM + 1 / BN): 64 x 64 tiles ran every prefill GEMM of the 1.7B talker at 12-14 TB/s of L2 reads (the chip's
+// practical limit for re-read lines) and no faster than the split-K kernel; 128 x 128 halves that traffic.
+template <int WM, int WN, int PF>
+__global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int A_BYTES = BM * MID_BK * 2;                     // BM rows x 128 B, 16-B slots XOR-swizzled by row
+    constexpr int B_BYTES = (BN / 32) * (MID_BK / 16) * 1024;    // packed 1-KiB weight fragments, verbatim
+    constexpr int NA = BM / 32, NB = BN / 32;                    // 16-B pieces per thread and stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (A_BYTES + B_BYTES)];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // Workgroups are dealt round-robin over the 8 XCDs in launch order, each XCD with its own L2: XCD x takes the column tiles
+    // x, x + 8, ... and runs ALL row tiles of one column tile back to back, so a weight tile is fetched into one L2 once and
+    // re-read there by the other row tiles (the plain x-fastest order puts the row tiles of a column tile on different XCDs).
+    const int n_rt = (g.M + BM - 1) / BM, n_ct = (g.N + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ct = (jj / n_rt) * 8 + xcd, rt = jj % n_rt;
+    if (ct >= n_ct) return;
+    const int64_t m0 = (int64_t)rt * BM;
+    const int n0 = ct * BN;
+    const int n_it = g.K / MID_BK;
+    // A pieces: thread -> (row = tid >> 3 (+32 i), 16-B slot tid & 7); B pieces: thread -> fragment (tid >> 6) (+4 i), lane
+    const int a_row = tid >> 3, a_slot = tid & 7;
+    // Every request below is UNCONDITIONAL on a clamped address (a row past M re-reads row M - 1, a column tile past N the last
+    // tile, an iteration past the end the last one): rows / columns that do not exist only feed accumulator elements that are
+    // never stored, and with no branch around a load the compiler can wait for an older stage with a counted `s_waitcnt vmcnt(n)`
+    // instead of draining the loads it has just issued (a full round trip per iteration otherwise).
+    const bf16_t* a_src[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int64_t m = m0 + a_row + 32 * i;
+        if (m >= g.M) m = g.M - 1;
+        a_src[i] = g.A + m * g.K + a_slot * 8;
+    }
+    const int nt0 = n0 >> 5;
+    const s8_t* b_src[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = (tid >> 6) + 4 * i;                        // fragment f -> (column tile f >> 2, k tile f & 3)
+        int t_n = nt0 + (f >> 2);
+        if (t_n >= g.NT) t_n = g.NT - 1;
+        b_src[i] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)t_n * g.KT + (f & 3)) * 64 + lane;
+    }
+    struct Regs { s8_t a[NA], b[NB]; };
+    auto issue = [&](int it, Regs& rg) {
+        if (it >= n_it) it = n_it - 1;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) rg.a[i] = *reinterpret_cast<const s8_t*>(a_src[i] + (int64_t)it * MID_BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rg.b[i] = b_src[i][(int64_t)it * (MID_BK / 16) * 64];
+    };
+    auto stash = [&](int buf, const Regs& rg) {
+        unsigned char* base = lds + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = a_row + 32 * i;
+            *reinterpret_cast<s8_t*>(base + row * 128 + ((a_slot ^ (row & 7)) << 4)) = rg.a[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<s8_t*>(base + A_BYTES + ((tid >> 6) + 4 * i) * 1024 + lane * 16) = rg.b[i];
+    };
+    f16_t acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    auto multiply = [&](int buf) {
+        const unsigned char* base = lds + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s8_t fa[WM], fb[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                const int row = (wm * WM + a) * 32 + r;
+                fa[a] = *reinterpret_cast<const s8_t*>(base + row * 128 + (((kt * 2 + h) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < WN; ++b) fb[b] = *reinterpret_cast<const s8_t*>(base + A_BYTES + ((wn * WN + b) * 4 + kt) * 1024 + lane * 16);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = mfma32(fa[a], fb[b], acc[a][b]);
+        }
+    };
+    // stage s: requested at iteration s - PF into register set s % PF, stashed at the end of iteration s - 1, multiplied at
+    // iteration s (PF even: the LDS buffer of stage it + j is j & 1 whenever it is a multiple of PF)
+    static_assert(PF % 2 == 0, "PF even");
+    Regs rg[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) issue(j, rg[j]);
+    stash(0, rg[0]);
+    __syncthreads();
+    int it = 0;
+    for (; it + PF <= n_it; it += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            issue(it + j + PF, rg[j]);                   // (rg[j] held stage it + j, stashed an iteration ago)
+            multiply(j & 1);
+            stash((j + 1) & 1, rg[(j + 1) % PF]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) {
+        if (it + j < n_it) {
+            multiply(j & 1);
+            stash((j + 1) & 1, rg[j + 1]);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            const int n = n0 + (wn * WN + b) * 32 + r;
+            if (n >= g.N) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = m0 + (wm * WM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < g.M) g.out[m * g.ldc + n] = acc[a][b][i];
+            }
+        }
+}
+
 // Causal dilated conv as an implicit GEMM with the input window held in LDS (codec decoder k=7 convs, operand = hi / lo bf16
 // planes).  k_gemm_tiled walks K = tap x channel in 32-wide steps and re-loads a shifted copy of the same input rows for every
 // tap: 7 global loads, 7 barriers and 7 exposed round trips per 32 channels.  Here a workgroup loads the rows its 128 outputs
@@ -759,6 +902,24 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
     else
         hipExtLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
                               KT / split_k, d_out, ldc, w.N);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int g_prefill_mid = 1;           // 1: prompt prefills of 65..1024 rows run their GEMMs on k_gemm_mid (no split-K slabs); 2 / 3 force its 64 / 128 tiles
+bool gemm_mid_ok(int M, const PackedW& w) { return g_prefill_mid && M > 64 && M <= 1024 && w.K % MID_BK == 0 && w.K >= 128 && w.Kp == w.K; }
+int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc) {
+    if (!gemm_mid_ok(M, w)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_mid: M=%d K=%d outside its range", M, w.K);
+    MidArgs g{A, w.data, out, M, w.N, w.K, w.Np / 32, w.Kp / 16, ldc};
+    // 128 x 128 tiles only where they still give >= 2 workgroups per CU (the gate/up projection: 42.7 vs 57 us at M = 460);
+    // with 64-128 workgroups a 128-tile launch ran 25-42 us against 21-23 us for 64 x 64 (one workgroup per CU cannot overlap its
+    // LDS phase with its MFMA phase)
+    const bool big = g_prefill_mid == 1 ? (int64_t)((M + 127) / 128) * ((w.N + 127) / 128) >= 2 * ctx->n_cu * 3 / 4 : g_prefill_mid == 3;      // (2 / 3: 64 x 64 / 128 x 128 tiles forced)
+    const int bm = big ? 128 : 64;
+    const int n_rt = (M + bm - 1) / bm, n_ct = (w.N + bm - 1) / bm;
+    dim3 grid(8 * ((n_ct + 7) / 8) * n_rt);               // (XCD-aware order, see the kernel)
+    if (big) hipLaunchKernelGGL((k_gemm_mid<2, 2, 4>), grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_gemm_mid<1, 1, 6>), grid, dim3(256), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

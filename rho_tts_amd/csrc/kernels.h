@@ -69,6 +69,10 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
 size_t packed16_bytes(int N, int K);
 int launch_pack_weight16(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
 int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e);
+// prompt-prefill GEMM (65..1024 rows): out[M][N] f32 = A[M][K] bf16 . W^T, whole K per 64 x 64 tile, final sums (no slabs)
+extern int g_prefill_mid;
+bool gemm_mid_ok(int M, const PackedW& w);
+int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc);
 // Weight-streaming form for M <= 64 rows (decode): plain bf16 A [M][K], raw f32 slabs out.
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -328,6 +328,9 @@ int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* s
         prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
         RT_TRY(launch_gemm_skinny(m->ctx, A, rows, W, slabs, W.N, S, e0, e1));
         *n_slabs = S;
+    } else if (gemm_mid_ok(rows, W)) {
+        RT_TRY(launch_gemm_mid(m->ctx, A, rows, W, slabs, W.N));   // prompt prefill: final sums from 64 x 64 tiles over the whole K
+        *n_slabs = 1;
     } else {
         // prefill: a few hundred rows give only a handful of 128x128 tiles; split K until the grid covers the chip
         const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);

@@ -52,6 +52,26 @@ def test_skinny_gemm_matches_fp32(ctx, M, N, K, split):
     assert torch.equal(gemm(ctx, ai, wi, mode=1, split_k=split), ai.float() @ wi.float().T)
 
 
+@pytest.mark.parametrize("M,N,K", [(460, 2048, 2048), (416, 4096, 2048), (460, 2048, 6144), (65, 96, 192), (129, 64, 256), (1000, 160, 320),
+                                   (333, 12288, 2048)])
+def test_prefill_gemm_matches_fp32(ctx, M, N, K):
+    """k_gemm_mid (prompt prefill, 65..1024 rows, whole K per 64 x 64 tile, final sums): the prefix / suffix prefill shapes of the
+    1.7B preset, row and column tails, the shortest K; integer-valued operands bit-exact."""
+    a = rnd(M, K, seed=1).to(torch.bfloat16).cuda()
+    w = rnd(N, K, scale=0.05, seed=2).to(torch.bfloat16).cuda()
+    ai = torch.randint(-4, 5, (M, K), generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).cuda()
+    wi = torch.randint(-4, 5, (N, K), generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
+    ref = a.float() @ w.float().T
+    try:
+        for code in (1902, 1903, 1901):              # 64 x 64 tiles, 128 x 128 tiles, the automatic choice
+            ctx.lib.rt_debug_tune(code, 0)
+            out = gemm(ctx, a, w, mode=2)
+            assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), code
+            assert torch.equal(gemm(ctx, ai, wi, mode=2), ai.float() @ wi.float().T), code
+    finally:
+        ctx.lib.rt_debug_tune(1901, 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (1000, 96, 672), (5, 40, 16), (257, 384, 2048)])
 @pytest.mark.parametrize("f32", [False, True])
 def test_tiled_gemm_matches_fp32(ctx, M, N, K, f32):
