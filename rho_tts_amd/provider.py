@@ -428,6 +428,24 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
             return float(eng.frames_for(segment, len(eng.tokenizer.encode(segment))))
         return float(max(1, len(segment.split())))
 
+    def _compute_speaker_similarity(self, wav_tensor: torch.Tensor) -> float:
+        """Cosine similarity between generated audio and the reference voice (base_tts.py:325-346, which embeds both with
+        resemblyzer on the CPU and is never called by the reference's own pipeline).  Here both embeddings come from the model's
+        OWN speaker encoder on the GPU - the statistics-pooling head of the audio encoder that also conditions the talker
+        (rt_voice_encode) - so the score says how close the output is in the space the model itself clones from.  Not comparable
+        in value with resemblyzer's; same range and direction (1 = same voice)."""
+        eng = self._load_engine()
+        with self._lock:
+            self._ensure_voice(eng)
+            ref = None if eng.voice is None else eng.voice.speaker_embed
+            if ref is None:
+                raise ValueError("speaker similarity needs a cloned voice (reference audio with a Base model)")
+            pcm = wav_tensor.detach().to(torch.float32).reshape(-1).cpu().numpy()
+            cap = eng.model.rt_cfg.enc.max_ref_frames * eng.cfg.codec.total_upsample     # (samples the encoder's frame budget covers)
+            _, emb = eng.model.encode_voice(pcm[:cap])
+        ref = ref.detach().to(torch.float32).cpu().reshape(-1)
+        return float(torch.dot(ref, emb) / (ref.norm() * emb.norm()).clamp_min(1e-12))
+
     def _cut_batches(self, todo: List[int], work, bs: int) -> List[List[int]]:
         """The engine decodes any number of segments on its ``batch_size`` rows with continuous batching (finished rows are handed
         to the next queued segment, Engine.synthesize): the whole work list goes down in one call instead of being cut here."""

@@ -129,6 +129,20 @@ def test_generate_through_the_factory(tiny_provider, tmp_path):
     p.seed = 789
 
 
+def test_speaker_similarity_on_the_models_own_encoder(tiny_provider):
+    """_compute_speaker_similarity (base_tts.py:325-346) on the GPU speaker encoder: the reference clip against itself is 1,
+    a different signal scores lower, the value is a cosine."""
+    p = tiny_provider
+    with wave.open(p.reference_audio_path, "rb") as wf:
+        ref = np.frombuffer(wf.readframes(wf.getnframes()), "<i2").astype(np.float32) / 32768.0
+    same = p._compute_speaker_similarity(torch.from_numpy(ref))
+    assert abs(same - 1.0) < 1e-4, same
+    g = torch.Generator().manual_seed(5)
+    noise = 0.1 * torch.randn(SR, generator=g)
+    other = p._compute_speaker_similarity(noise.cuda())
+    assert -1.0 <= other < same - 1e-3, other
+
+
 def test_batched_equals_one_at_a_time(tiny_provider):
     p = tiny_provider
     texts = ["Alpha beta gamma delta", "One two", "A somewhat longer piece of text to speak here"]
