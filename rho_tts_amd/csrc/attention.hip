@@ -262,7 +262,10 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
     }
     // few rows with long contexts (the talker's decode step over a long KV row): 16 waves split the positions;
     // many rows or short contexts (prefill, predictor, sliding window): 4 waves are plenty
-    const bool wide = M * kv_heads <= 512 && kv.max_pos > 64 && (window <= 0 || window > 256);
+    // (decode steps only - the fused form, or frame-indexed rows: a PROMPT row must be attended with the same wave split,
+    //  i.e. the same float32 merge order, whether it is prefilled alone or among 400 rows - a text's audio may not depend on
+    //  what it was batched with)
+    const bool wide = (FUSED || f0.frame_ptr) && M * kv_heads <= 512 && kv.max_pos > 64 && (window <= 0 || window > 256);
 #define RT_ATT(DD)                                                                                                                   \
     return wide ? dispatch_rep<DD, FUSED, 16>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f) \
                 : dispatch_rep<DD, FUSED, 4>(ctx, rep, grid, q, heads, kv_heads, row_slot, row_pos, pos_add, window, kc, vc, kv.max_pos, out, f)

@@ -522,10 +522,15 @@ struct MidArgs {
     float* out;
     int M, N, K, NT, KT;
     int64_t ldc;
+    int seg_it;        // > 0: every seg_it iterations the accumulator is added to a running total and cleared (see below)
 };
 // WM x WN 32 x 32 MFMA tiles per wave, 2 x 2 waves: the workgroup tile is (64 WM) x (64 WN).  Cache-to-CU traffic is
 // M N K 2 B x (1 / BM + 1 / BN): 64 x 64 tiles ran every prefill GEMM of the 1.7B talker at 12-14 TB/s of L2 reads (the chip's
 // practical limit for re-read lines) and no faster than the split-K kernel; 128 x 128 halves that traffic.
+// seg_it: a prompt row must get the SAME float32 sums whether it is prefilled among 460 rows here or among 13 rows by the
+// skinny kernel (continuous batching hands rows over a few at a time; a text's audio may not depend on its batch).  The skinny
+// kernel accumulates K in `split` contiguous segments and its consumers add the segment sums in order; with seg_it this
+// kernel adds in exactly that association: ascending k inside a segment, then total = (...((0 + s0) + s1) + ...).
 template <int WM, int WN, int PF>
 __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -586,13 +591,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<s8_t*>(base + A_BYTES + ((tid >> 6) + 4 * i) * 1024 + lane * 16) = rg.b[i];
     };
-    f16_t acc[WM][WN];
+    f16_t acc[WM][WN], tot[WM][WN];
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
         for (int b = 0; b < WN; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+            for (int i = 0; i < 16; ++i) { acc[a][b][i] = 0.f; tot[a][b][i] = 0.f; }
+    int seg_left = g.seg_it;
+    auto flush = [&]() {                       // end of a K segment (uniform branch): total += segment sum
+        if (g.seg_it > 0 && --seg_left == 0) {
+            seg_left = g.seg_it;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { tot[a][b][i] += acc[a][b][i]; acc[a][b][i] = 0.f; }
+        }
+    };
     auto multiply = [&](int buf) {
         const unsigned char* base = lds + buf * (A_BYTES + B_BYTES);
 #pragma unroll
@@ -625,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
         for (int j = 0; j < PF; ++j) {
             issue(it + j + PF, rg[j]);                   // (rg[j] held stage it + j, stashed an iteration ago)
             multiply(j & 1);
+            flush();
             stash((j + 1) & 1, rg[(j + 1) % PF]);
             __syncthreads();
         }
@@ -633,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
     for (int j = 0; j < PF - 1; ++j) {
         if (it + j < n_it) {
             multiply(j & 1);
+            flush();
             stash((j + 1) & 1, rg[j + 1]);
             __syncthreads();
         }
@@ -646,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int64_t m = m0 + (wm * WM + a) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < g.M) g.out[m * g.ldc + n] = acc[a][b][i];
+                if (m < g.M) g.out[m * g.ldc + n] = g.seg_it > 0 ? tot[a][b][i] : acc[a][b][i];
             }
         }
 }
@@ -910,15 +929,19 @@ int g_prefill_mid = 1;           // 1: prompt prefills of 65..1024 rows run thei
 bool gemm_mid_ok(int M, const PackedW& w) { return g_prefill_mid && M > 64 && M <= 1024 && w.K % MID_BK == 0 && w.K >= 128 && w.Kp == w.K; }
 int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc) {
     if (!gemm_mid_ok(M, w)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_mid: M=%d K=%d outside its range", M, w.K);
-    MidArgs g{A, w.data, out, M, w.N, w.K, w.Np / 32, w.Kp / 16, ldc};
-    // 128 x 128 tiles only where they still give >= 2 workgroups per CU (the gate/up projection: 42.7 vs 57 us at M = 460);
-    // with 64-128 workgroups a 128-tile launch ran 25-42 us against 21-23 us for 64 x 64 (one workgroup per CU cannot overlap its
-    // LDS phase with its MFMA phase)
-    const bool big = g_prefill_mid == 1 ? (int64_t)((M + 127) / 128) * ((w.N + 127) / 128) >= 2 * ctx->n_cu * 3 / 4 : g_prefill_mid == 3;      // (2 / 3: 64 x 64 / 128 x 128 tiles forced)
+    MidArgs g{A, w.data, out, M, w.N, w.K, w.Np / 32, w.Kp / 16, ldc, 0};
+    // same association of the K sum as the skinny kernel's slabs (its split depends on N and K only): see the kernel
+    const int S = skinny_pick_split(M, w.N, w.K, ctx->n_cu);
+    if (S > 1 && (g.KT / S) % (MID_BK / 16) == 0) g.seg_it = (g.KT / S) / (MID_BK / 16);
+    // 128 x 64 tiles (3/4 of the cache-to-CU traffic of 64 x 64) only where they still give >= 3 workgroups per CU - the
+    // gate/up projection; with fewer, a bigger tile cannot overlap its LDS phase with its MFMA phase (128 x 128 tiles at M = 460:
+    // 25-42 us on the 64-128 workgroups of the narrow projections against 21-23 us for 64 x 64, 42.7 us on gate/up - but with the
+    // segment totals they need 2 x 64 accumulator registers on top of the staging registers and spill)
+    const bool big = g_prefill_mid == 1 ? (int64_t)((M + 127) / 128) * ((w.N + 63) / 64) >= 3 * ctx->n_cu : g_prefill_mid == 3;      // (2 / 3: forced)
     const int bm = big ? 128 : 64;
-    const int n_rt = (M + bm - 1) / bm, n_ct = (w.N + bm - 1) / bm;
+    const int n_rt = (M + bm - 1) / bm, n_ct = (w.N + 63) / 64;
     dim3 grid(8 * ((n_ct + 7) / 8) * n_rt);               // (XCD-aware order, see the kernel)
-    if (big) hipLaunchKernelGGL((k_gemm_mid<2, 2, 4>), grid, dim3(256), 0, ctx->stream, g);
+    if (big) hipLaunchKernelGGL((k_gemm_mid<2, 1, 4>), grid, dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((k_gemm_mid<1, 1, 6>), grid, dim3(256), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;

@@ -1078,8 +1078,9 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // wait in a queue: whenever the host learns (every g_handover_every frames) that rows have finished, the next queued
     // items take them over - their prompt suffixes are prefilled into the rows' KV slots between two frames, the rows'
     // state / position base / RNG stream / repetition history are re-pointed - so that every weight pass keeps serving
-    // live rows.  An item's result depends only on (item id, seed): the same codes as in any static batch, up to the
-    // float32 summation order of its prompt prefill (whose GEMM shape depends on how many suffix rows are prefilled together).
+    // live rows.  An item's result depends only on (item id, seed): bit for bit the codes it gets in any static batch or
+    // alone - the prompt prefill gives a row the same float32 sums whatever it is batched with (k_gemm_mid adds K in the
+    // skinny kernel's segments, prompt attention always runs the 4-wave split), decode rows never see each other.
     const int N = A->n_items, G = c.n_groups, H = c.talker.hidden, Hp = c.predictor.hidden, Vc = c.codec_vocab, Vp = c.predictor_vocab;
     if (N < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: n_items %d < 1", N);
     const int B = std::min(N, c.max_batch);

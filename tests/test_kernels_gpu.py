@@ -63,13 +63,33 @@ def test_prefill_gemm_matches_fp32(ctx, M, N, K):
     wi = torch.randint(-4, 5, (N, K), generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
     ref = a.float() @ w.float().T
     try:
-        for code in (1902, 1903, 1901):              # 64 x 64 tiles, 128 x 128 tiles, the automatic choice
+        for code in (1902, 1903, 1901):              # 64 x 64 tiles, 128 x 64 tiles, the automatic choice
             ctx.lib.rt_debug_tune(code, 0)
             out = gemm(ctx, a, w, mode=2)
             assert float((out - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), code
             assert torch.equal(gemm(ctx, ai, wi, mode=2), ai.float() @ wi.float().T), code
     finally:
         ctx.lib.rt_debug_tune(1901, 0)
+
+
+@pytest.mark.parametrize("N,K", [(2048, 2048), (4096, 2048), (12288, 2048), (2048, 6144), (3072, 2048)])
+def test_prefill_gemm_rows_do_not_depend_on_the_batch(ctx, N, K):
+    """A prompt row must get the same float32 sums whether it is prefilled among 460 rows (k_gemm_mid) or among a dozen (the
+    skinny kernel + its slab sum): the mid kernel adds K in the skinny kernel's segments and association.  Random operands,
+    bit for bit, on the 1.7B talker's four projection shapes and its head."""
+    a = rnd(460, K, seed=5).to(torch.bfloat16).cuda()
+    w = rnd(N, K, scale=0.05, seed=6).to(torch.bfloat16).cuda()
+    big = {}
+    try:
+        for code in (1902, 1903):
+            ctx.lib.rt_debug_tune(code, 0)
+            big[code] = gemm(ctx, a, w, mode=2)
+    finally:
+        ctx.lib.rt_debug_tune(1901, 0)
+    assert torch.equal(big[1902], big[1903])                           # 64- and 128-row tiles: same sums
+    for r0, m in ((0, 13), (100, 33), (396, 64)):
+        small = gemm(ctx, a[r0:r0 + m].contiguous(), w, mode=1, split_k=0)   # the skinny kernel with its production split
+        assert torch.equal(small, big[1902][r0:r0 + m]), (r0, m)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (1000, 96, 672), (5, 40, 16), (257, 384, 2048)])

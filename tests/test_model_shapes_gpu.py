@@ -141,12 +141,10 @@ def test_code2wav_at_real_codec_dimensions(ctx):
 
 def test_continuous_batching_at_the_bench_shape(ctx):
     """rt_generate with more items than rows on the 1.7B preset with the 460-row clone prefix: 44 ragged items on 32 rows.
-    The first 32 items' prompts are prefilled exactly as a static batch of those 32 prefills them (same GEMM shapes), so their
-    codes must equal that batch's bit for bit whatever happens on the other rows; the queued items go through a hand-over
-    prefill of a different shape (float32 summation order of the prompt differs: with random-weight logits full of near-ties a
-    sampled trajectory can legitimately fork at any code), so they are held to MOST first codes agreeing with the item alone
-    (bit-exact equality of queued items is pinned where the prefill shapes coincide: tests/test_model_gpu.py, tiny / small) -
-    and every item to its exact length and code range."""
+    Every item - the 32 that start on the rows and the 12 that take over finished rows after a hand-over prefill of a few rows -
+    must come out bit for bit as it does ALONE in a one-item call, and as the first 32 do in a static batch: the prompt
+    prefill gives a row the same float32 sums whatever it is batched with (k_gemm_mid adds K in the skinny kernel's
+    segments), decode rows never see each other, and the RNG stream is (item id, the item's own frame number)."""
     from rho_tts_amd._native_model import NativeModel, RtSampling
     from rho_tts_amd.tokenizer import HashTokenizer
     cfg = config.PRESETS["1.7b"]()
@@ -170,11 +168,8 @@ def test_continuous_batching_at_the_bench_shape(ctx):
         st = nm.generate_stats()
         assert [c.shape[0] for c in got] == frames and st["rows"] == 32 and st["hand_overs"] >= 1
         assert all(torch.equal(a, b) for a, b in zip(got[:32], static))
-        same = 0
-        for i in range(32, n):
+        for i in list(range(0, 32, 5)) + list(range(32, n)):
             alone = nm.generate([texts[i]], [frames[i]], sp, seed=9, item_ids=[ids[i]])[0]
-            same += int(got[i][0, 0] == alone[0, 0])                    # frame 0, group 0: same RNG stream, same prompt up to rounding
-            assert int(got[i].min()) >= 0 and int(got[i].max()) < max(cfg.codec.codebook_size, cfg.predictor_vocab)
-        assert same >= 0.75 * (n - 32), same
+            assert torch.equal(got[i], alone), i
     finally:
         nm.close()
