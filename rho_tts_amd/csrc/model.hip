@@ -347,10 +347,12 @@ int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* s
 
 // float32 rows (fed as hi + lo bf16 planes, split on load) times W^T -> raw f32 slabs: the float32-faithful form of gemm_rows
 int gemm_rows_f32(rt_model* m, const float* A, int rows, const PackedW& W, float* slabs, int* n_slabs) {
-    const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);
-    int S = 1;
+    // The split depends on the weight's shape ONLY, never on the number of rows: a codec frame must get the same float32 sums
+    // whether its item is vocoded alone or in a batch of 32 (the waveform of a text may not depend on what it was batched with).
     // (slab workspace: 8 slabs for > 64 rows, 64 x 32768 floats otherwise - slab_floats)
-    while (S < 8 && tiles * S < g_prefill_fill * m->ctx->n_cu && W.K / (S * 2) >= 256 && (rows > 64 || (int64_t)S * 2 * W.N <= 32768)) S *= 2;
+    (void)rows;
+    int S = 1;
+    while (S < 8 && W.K / (S * 2) >= 256 && (int64_t)S * 2 * W.N <= 32768) S *= 2;
     GemmA a; a.ptr = A; a.is_f32 = 1; a.split = 1; a.M = rows; a.Cin = W.K; a.taps = 1;
     GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = S;
     RT_TRY(launch_gemm(m->ctx, a, W, e));

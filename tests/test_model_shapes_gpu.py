@@ -135,6 +135,10 @@ def test_code2wav_at_real_codec_dimensions(ctx):
             print(f"\\ncode2wav {c.shape[0]} frames: rmse {rmse:.2e}, ref rms {float(ref.pow(2).mean().sqrt()):.3f}")
             assert rmse < 1e-3, rmse
             assert float(ref.abs().max()) > 0.05
+        # the waveform of an item does not depend on what it is vocoded with: alone == beside a longer item, bit for bit
+        # (no split or tile choice in the decoder depends on the number of rows)
+        for c, w in zip(codes, wavs):
+            assert torch.equal(nm.code2wav([c])[0], w)
     finally:
         nm.close()
 
