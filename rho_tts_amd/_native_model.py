@@ -454,7 +454,9 @@ class NativeModel:
             a.d_trace_predictor = tr["predictor"].data_ptr()
         self.ctx.check(self.lib.rt_generate(self.handle, C.byref(a)), "rt_generate")
         out, off = [], 0
-        flat_codes = torch.tensor(list(codes), dtype=torch.int64).reshape(-1, G) if tot else torch.zeros(0, G, dtype=torch.int64)
+        import numpy as np
+        flat_codes = (torch.from_numpy(np.frombuffer(codes, dtype=np.int32).astype(np.int64)).reshape(-1, G) if tot
+                      else torch.zeros(0, G, dtype=torch.int64))     # (a view of the ctypes buffer: no per-element Python objects)
         for b in range(B):
             out.append(flat_codes[off: off + nfr[b]].clone())
             off += int(max_frames[b])
