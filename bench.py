@@ -251,7 +251,7 @@ def main():
                       # `planned` is what static length-bucketed batches of the same shards would give
                       "padding_efficiency": round(sched.get("frames", 0) / max(1, sched.get("padded_frames", 1)), 4),
                       "padding_efficiency_static_plan": round(pad_eff, 4),
-                      "schedule": "static length-bucketed batches" if (args.static_batches or B > 32) else "continuous batching (finished rows handed to queued texts)",
+                      "schedule": "static length-bucketed batches" if (args.static_batches or B > 64) else "continuous batching (finished rows handed to queued texts)",
                       "row_hand_overs_per_step": sched.get("hand_overs", 0) // max(1, args.steps),
                       "batches_per_rank_static_plan": [len(pl) for pl in plans]})
 
@@ -276,7 +276,8 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "audio-sec/wall-sec (RTF) Qwen3-TTS-1.7B batch=32",
+            # BASELINE.json's metric at the default flags; any other model / batch is named as what it is
+            "metric": f"audio-sec/wall-sec (RTF) Qwen3-TTS-{args.model.upper() if args.model[0].isdigit() else args.model} batch={B}",
             "value": round(audio_total / dt, 2),
             "unit": "audio-s/s",
             "n_gpus": world,
@@ -291,7 +292,7 @@ def main():
             "config": {"workload": (f"{cfg.name} bf16, batch {B}/GPU, {args.ref_seconds:g}-s reference clone, "
                                     + (f"{args.words}-word sentences ({eng.frames_for(texts[0], 0)} frames each)" if corpus is None else
                                        f"ONE corpus of {len(corpus)} texts of 6-24 words ({min(c_frames)}-{max(c_frames)} frames) sharded by length over the ranks, "
-                                       + ("length-bucketed static batches" if (args.static_batches or B > 32) else "continuous batching on the rank's decode rows"))
+                                       + ("length-bucketed static batches" if (args.static_batches or B > 64) else "continuous batching on the rank's decode rows"))
                                     + f", sampling={'greedy' if args.greedy else 'top-k 50 T 0.9'}, seeded synthetic weights; "
                                     "value counts delivered (post-processed) audio"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},

@@ -36,7 +36,7 @@ extern "C" {
 
 #define RT_API __attribute__((visibility("default")))
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -261,6 +261,9 @@ typedef struct rt_generate_args {
     int32_t* h_n_frames;            /* out: [n_items]                                              */
     float* d_trace_talker;          /* optional: [max_frames_max][n_items][codec_vocab] talker logits */
     float* d_trace_predictor;       /* optional: [max_frames_max][n_groups-1][n_items][predictor_vocab] */
+    int32_t max_rows;               /* 0: decode on min(n_items, max_batch) rows; else on at most this many (a short queue is
+                                       served faster by 32 busy rows than by 64 half-empty ones: a 64-row frame costs ~1.4x a
+                                       32-row one)                                                                           */
 } rt_generate_args;
 
 RT_API int rt_generate(rt_model* m, const rt_generate_args* args);
@@ -330,6 +333,7 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame) |
  *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores | 1600/1601 quarter-tile split off/on |
  *   17nn queued items (rt_generate with n_items > max_batch) take over finished rows every nn frames (default 4) |
+ *   20nn batches of up to nn rows (default 64) decode on the column-owner path, larger ones on the legacy split-K path |
  *   1900/1901/1902/1903 prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid (automatic, 64 x 64, 128 x 128 tiles) |
  *   1800/1801/1802 narrow-channel (96 / 192) k>1 convs on 128-row tiles / 256-row tiles for long inputs / 256-row tiles always
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose

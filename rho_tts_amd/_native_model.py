@@ -46,7 +46,7 @@ class RtGenerateArgs(C.Structure):
                 ("tts_eos_id", C.c_int32), ("tts_pad_id", C.c_int32), ("codec_pad_id", C.c_int32), ("codec_bos_id", C.c_int32),
                 ("h_forced_codes", C.POINTER(C.c_int32)), ("h_forced_offsets", C.POINTER(C.c_int32)),
                 ("h_cancel_flag", C.POINTER(C.c_int32)), ("h_codes", C.POINTER(C.c_int32)), ("h_n_frames", C.POINTER(C.c_int32)),
-                ("d_trace_talker", C.c_void_p), ("d_trace_predictor", C.c_void_p)]
+                ("d_trace_talker", C.c_void_p), ("d_trace_predictor", C.c_void_p), ("max_rows", C.c_int32)]
 
 
 def declare(lib: C.CDLL) -> None:
@@ -406,7 +406,7 @@ class NativeModel:
     # ------------------------------------------------------------------ decode
     def generate(self, texts: Sequence[Sequence[int]], max_frames: Sequence[int], talker=None, predictor=None, seed: int = 789,
                  item_ids: Optional[Sequence[int]] = None, ignore_eos: bool = True, min_frames: int = 2,
-                 forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: bool = False, cancel_flag=None):
+                 forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: bool = False, cancel_flag=None, max_rows: int = 0):
         c = self.cfg
         B, G = len(texts), c.n_groups
         talker = talker or RtSampling(0, 0.9, 50, 1.0, 1.0)
@@ -425,6 +425,7 @@ class NativeModel:
         a.seed = seed
         a.talker, a.predictor = talker, predictor
         a.ignore_eos, a.min_frames = int(ignore_eos), min_frames
+        a.max_rows = int(max_rows)
         a.tts_eos_id, a.tts_pad_id, a.codec_pad_id, a.codec_bos_id = c.tts_eos_id, c.tts_pad_id, c.codec_pad_id, c.codec_bos_id
         keep = []
         if forced_codes is not None:

@@ -865,6 +865,9 @@ int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one laun
 int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
 int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
 int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its own LDS-window kernel
+int g_col_max_rows = 64;         // batches up to this many rows decode on the column-owner path (tune 20nn).  Above 32 the talker's GEMMs take 64 rows per
+                                // launch and the predictor's two-position first pass runs as two 64-row launches: 715 audio-s/s at batch 64 against
+                                // 510 at batch 32 (1.7B, bench.py --batch 64) - every weight byte serves twice the rows for ~1.4x the launch time
 int g_conv_tall = 1;            // 1: 256-row tiles for the k>1 convs of the 96- / 192-channel stages
 int g_conv_win = 1;             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
 int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128

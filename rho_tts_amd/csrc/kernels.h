@@ -85,6 +85,7 @@ extern int g_sync_parts;
 extern int g_eos_check_every;
 extern int g_handover_every;
 extern int g_conv_tall;
+extern int g_col_max_rows;
 extern int g_tile96;
 extern int g_conv_win;
 extern int g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM

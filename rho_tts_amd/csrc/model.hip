@@ -1085,7 +1085,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     // skinny kernel's segments, prompt attention always runs the 4-wave split), decode rows never see each other.
     const int N = A->n_items, G = c.n_groups, H = c.talker.hidden, Hp = c.predictor.hidden, Vc = c.codec_vocab, Vp = c.predictor_vocab;
     if (N < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: n_items %d < 1", N);
-    const int B = std::min(N, c.max_batch);
+    const int B = std::min(N, A->max_rows > 0 ? std::min(A->max_rows, c.max_batch) : c.max_batch);
     const bool queued = N > B;
     if (!A->h_text_ids || !A->h_text_offsets || !A->h_max_frames || !A->h_item_ids || !A->h_codes || !A->h_n_frames)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_generate: null array");
@@ -1219,7 +1219,7 @@ int rt_generate(rt_model* m, const rt_generate_args* A) {
     RT_HIP(ctx, hipMemcpyAsync(d_seed, &A->seed, 8, hipMemcpyHostToDevice, ctx->stream));
     const int64_t codes_fs = (int64_t)B * G;
     // Column path (2B <= 64): xt = un-normalised talker residual stream + rowsq_t; legacy path: hn = final-norm output
-    const bool col = g_decode_col && 2 * B <= 64 && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 && c.predictor.inter % 32 == 0;
+    const bool col = g_decode_col && B <= g_col_max_rows && H % 32 == 0 && Hp % 32 == 0 && c.talker.inter % 32 == 0 && c.predictor.inter % 32 == 0;
     const int NTt = H / 16 * col_split_for(H, ctx->n_cu), NTp = Hp / 16 * col_split_for(Hp, ctx->n_cu);   // rowsq partials per row
     const PackedW& head = PW(m, "talker.codec_head");
     float* x_all = x;

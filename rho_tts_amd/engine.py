@@ -132,7 +132,7 @@ class Engine:
 
     # ------------------------------------------------------------------ generate
     def generate_codes(self, texts: Sequence[str], seed: int, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
-                       max_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+                       max_frames: Optional[Sequence[int]] = None, max_rows: int = 0) -> List[torch.Tensor]:
         if self.voice is None:
             raise ValueError("no voice set: reference audio (Base models) or a built-in speaker (CustomVoice) is required")
         ids = [self.tokenizer.encode(t) for t in texts]
@@ -143,7 +143,7 @@ class Engine:
                 raise RuntimeError(f"length: text of {len(i)} tokens + {f} frames exceeds the {limit} free KV rows")
         ignore_eos = self.synthetic if self.ignore_eos is None else bool(self.ignore_eos)
         return self.model.generate(ids, frames, self.params.talker(), self.params.predictor(), seed=seed, item_ids=item_ids,
-                                   ignore_eos=ignore_eos, cancel_flag=cancel_flag)
+                                   ignore_eos=ignore_eos, cancel_flag=cancel_flag, max_rows=max_rows)
 
     def vocode(self, codes: Sequence[torch.Tensor]) -> List[torch.Tensor]:
         """Codec decoder with the reference architecture's chunking (chunk_frames + left_context_frames)."""
@@ -194,10 +194,14 @@ class Engine:
         plan = [int(f) for f in plan_frames] if plan_frames is not None else frames
         wavs: List[Optional[torch.Tensor]] = [None] * n
         if continuous is None:
-            continuous = n > self.max_batch and self.max_batch <= 32       # (the column decode path serves <= 32 rows)
-        if continuous and n > self.max_batch:
+            # (the column decode path serves <= 64 rows; a 33..95-text queue on a 64-row engine goes to 32 busy rows, see below)
+            continuous = (n > self.max_batch or (self.max_batch > 32 and 32 < n < 96)) and self.max_batch <= 64
+        if continuous and (n > self.max_batch or (self.max_batch > 32 and 32 < n < 96)):
             order = sorted(range(n), key=lambda i: (-plan[i], i))          # longest first: short items fill the tail of the schedule
-            codes = self.generate_codes([texts[i] for i in order], seed, [ids[i] for i in order], cancel_flag, [frames[i] for i in order])
+            # a 64-row frame costs ~1.4x a 32-row one: a queue shorter than ~3 x 32 texts is served faster by 32 busy rows
+            rows = 32 if (self.max_batch > 32 and n < 96) else 0
+            codes = self.generate_codes([texts[i] for i in order], seed, [ids[i] for i in order], cancel_flag, [frames[i] for i in order],
+                                        max_rows=rows)
             st = self.model.generate_stats()
             by_len = sorted(range(n), key=lambda j: (-int(codes[j].shape[0]), j))
             for j, w in zip(by_len, self.vocode([codes[j] for j in by_len])):

@@ -449,7 +449,7 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
     def _cut_batches(self, todo: List[int], work, bs: int) -> List[List[int]]:
         """The engine decodes any number of segments on its ``batch_size`` rows with continuous batching (finished rows are handed
         to the next queued segment, Engine.synthesize): the whole work list goes down in one call instead of being cut here."""
-        if len(todo) > bs and bs <= 32:
+        if len(todo) > bs and bs <= 64:
             return [list(todo)]
         return super()._cut_batches(todo, work, bs)
 

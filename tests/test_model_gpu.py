@@ -337,34 +337,41 @@ def test_engine_chunked_vocode_matches_oracle_chunked_decode(ctx):
         eng.close()
 
 
-def test_batches_above_32_fall_back_to_the_split_k_path(ctx):
-    """2B > 64 rows do not fit the column-owner launches: the legacy split-K decode path takes over.  Teacher-forced logits of
-    a 36-item batch agree with the same items decoded in two 18-item batches on the column path."""
+@pytest.mark.parametrize("preset", ["tiny", "small"])
+def test_64_rows_on_the_column_path(ctx, preset):
+    """Batches of 33..64 rows decode on the column-owner path too (the talker's GEMMs take 64 rows per launch, the predictor's
+    two-position first pass runs as two 64-row launches): 50 ragged items in ONE static batch come out bit for bit as each does
+    alone; and the legacy split-K path (rt_debug_tune(2032): rows above 32 fall back to it) still agrees to float tolerance."""
     from rho_tts_amd._native_model import RtSampling
-    cfg = config.PRESETS["tiny"]()
-    nm, _ = build(ctx, cfg, max_batch=40)
+    cfg = config.PRESETS[preset]()
+    nm, _ = build(ctx, cfg, max_batch=64)
     try:
         set_voice(nm, make_voice(cfg, True))
         g = torch.Generator().manual_seed(17)
-        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(n),), generator=g)] for n in torch.randint(1, 7, (36,), generator=g)]
-        frames = [4] * 36
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(n),), generator=g)] for n in torch.randint(1, 7, (50,), generator=g)]
+        frames = [int(v) for v in torch.randint(3, 9, (50,), generator=g)]
         sp = RtSampling(1, 0.9, 50, 1.0, 1.05)
-        free = nm.generate(texts[:18], frames[:18], sp, seed=5, item_ids=list(range(18))) + \
-            nm.generate(texts[18:], frames[18:], sp, seed=5, item_ids=list(range(18, 36)))
+        alone = [nm.generate([t], [f], sp, seed=5, item_ids=[i])[0] for i, (t, f) in enumerate(zip(texts, frames))]
+        got = nm.generate(texts, frames, sp, seed=5, item_ids=list(range(50)))
+        assert all(torch.equal(a, b) for a, b in zip(got, alone))
+        # the legacy path on the same batch: teacher-forced logits within float tolerance of the column path's
         greedy = RtSampling(0, 1, 1, 1, 1)
-        out, tr_big = nm.generate(texts, frames, greedy, forced_codes=free, trace=True)
-        assert [o.shape[0] for o in out] == frames
-        _, tr_a = nm.generate(texts[:18], frames[:18], greedy, forced_codes=free[:18], trace=True)
-        _, tr_b = nm.generate(texts[18:], frames[18:], greedy, forced_codes=free[18:], trace=True)
+        f4 = [4] * 50
+        forced = [a[:4] if a.shape[0] >= 4 else torch.cat([a, a[-1:].repeat(4 - a.shape[0], 1)]) for a in alone]
+        _, tr_col = nm.generate(texts, f4, greedy, forced_codes=forced, trace=True)
+        nm.lib.rt_debug_tune(2032, 0)
+        try:
+            _, tr_leg = nm.generate(texts, f4, greedy, forced_codes=forced, trace=True)
+        finally:
+            nm.lib.rt_debug_tune(2064, 0)
         V0 = cfg.codec.codebook_size
         for key in ("talker", "predictor"):
-            big = tr_big[key].cpu()
-            small = torch.cat([tr_a[key].cpu(), tr_b[key].cpu()], dim=-2)       # the batch axis
+            a, b = tr_col[key].cpu(), tr_leg[key].cpu()
             if key == "talker":
-                big, small = big[..., :V0], small[..., :V0]
-            assert big.shape == small.shape
-            assert float((big - small).abs().max()) <= 0.06 * float(small.std()) + 1e-6
+                a, b = a[..., :V0], b[..., :V0]
+            assert float((a - b).abs().max()) <= 0.06 * float(b.std()) + 1e-6
     finally:
+        nm.lib.rt_debug_tune(2064, 0)
         nm.close()
 
 
