@@ -441,6 +441,9 @@ def test_queued_items_take_over_finished_rows(ctx, preset):
             got = nm.generate(texts, frames, live, seed=6, item_ids=ids, ignore_eos=False, min_frames=2)
             assert all(torch.equal(a, b) for a, b in zip(got, alone_live)), every
             assert nm.generate_stats()["frames_kept"] == sum(a.shape[0] for a in alone_live)
+        # fewer rows than the engine has (rt_generate_args::max_rows): same items, same codes, on 2 rows
+        got = nm.generate(texts, frames, fixed, seed=5, item_ids=ids, max_rows=2)
+        assert all(torch.equal(a, b) for a, b in zip(got, alone_fixed)) and nm.generate_stats()["rows"] == 2
         # a static batch afterwards still works (the graphs of the queued shape are not replayed for it)
         again = nm.generate(texts[:4], frames[:4], fixed, seed=5, item_ids=ids[:4])
         assert all(torch.equal(a, b) for a, b in zip(again, alone_fixed[:4]))
