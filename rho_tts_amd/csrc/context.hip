@@ -1,4 +1,7 @@
 // Context lifecycle of the C ABI (include/rho_tts_amd.h, "context" group).
+#include <cstdlib>
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 extern "C" {
@@ -34,7 +37,18 @@ int rt_create(int device_ordinal, rt_ctx** out_ctx) {
     ctx->device = device_ordinal;
     ctx->n_cu = prop.multiProcessorCount;
     snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    // RHO_TTS_AMD_CU_MASK="first:count" (measurement aid, tools/overlap_probe.py): the context's stream may only use that range of CUs
+    const char* cm = getenv("RHO_TTS_AMD_CU_MASK");
+    int first = 0, count = 0;
+    hipError_t se;
+    if (cm && sscanf(cm, "%d:%d", &first, &count) == 2 && first >= 0 && count > 0 && first + count <= ctx->n_cu) {
+        uint32_t mask[32] = {0};
+        for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
+        se = hipExtStreamCreateWithCUMask(&ctx->own_stream, (uint32_t)((ctx->n_cu + 31) / 32), mask);
+    } else {
+        se = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
     }

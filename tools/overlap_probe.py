@@ -10,8 +10,15 @@ from rho_tts_amd.engine import Engine
 from rho_tts_amd.voice import synthetic_reference_clip
 
 cfg = config.PRESETS["1.7b"]()
+# optional CU partition: overlap_probe.py 192  -> decode engine on CUs [0, 192), vocoder engine on [192, 256)
+split = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if split:
+    os.environ["RHO_TTS_AMD_CU_MASK"] = f"0:{split}"
 A = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32, synthetic=True)
+if split:
+    os.environ["RHO_TTS_AMD_CU_MASK"] = f"{split}:{256 - split}"
 B = Engine(cfg=cfg, model_path=cfg.name, device_ordinal=0, max_batch=32, synthetic=True)
+os.environ.pop("RHO_TTS_AMD_CU_MASK", None)
 texts = bench.sentences(32, 10, seed=789)
 clip = synthetic_reference_clip(30.0, cfg.sample_rate, 789)
 ref_text = " ".join(bench.WORDS[i % len(bench.WORDS)] for i in range(75))
