@@ -452,3 +452,39 @@ def test_queued_items_take_over_finished_rows(ctx, preset):
     finally:
         nm.lib.rt_debug_tune(1704, 0)
         nm.close()
+
+
+def test_queued_items_randomised(ctx):
+    """Continuous batching under random schedules (tiny preset): number of items 1..40, rows 1..8, budgets 1..12 frames (also a
+    single frame, also fewer items than rows), every polling period, fixed lengths and live end-of-sequence.  Each item must be
+    the prefix of what it produces alone with the largest budget (its RNG stream is (item id, its own frame number))."""
+    from rho_tts_amd._native_model import RtSampling
+    cfg = config.PRESETS["tiny"]()
+    nm, _ = build(ctx, cfg, max_batch=8)
+    try:
+        set_voice(nm, make_voice(cfg, True))
+        g = torch.Generator().manual_seed(99)
+        pool_n = 40
+        texts = [[int(v) for v in torch.randint(0, cfg.text_vocab - 64, (int(k),), generator=g)] for k in torch.randint(1, 9, (pool_n,), generator=g)]
+        ids = [1000 + 3 * i for i in range(pool_n)]
+        sp_fixed, sp_live = RtSampling(1, 0.9, 50, 1.0, 1.05), RtSampling(1, 1.5, 64, 1.0, 1.0)
+        full_fixed = [nm.generate([t], [12], sp_fixed, seed=3, item_ids=[i])[0] for t, i in zip(texts, ids)]
+        full_live = [nm.generate([t], [12], sp_live, seed=4, item_ids=[i], ignore_eos=False, min_frames=1)[0] for t, i in zip(texts, ids)]
+        for trial in range(24):
+            n = int(torch.randint(1, pool_n + 1, (1,), generator=g))
+            pick = torch.randperm(pool_n, generator=g)[:n].tolist()
+            frames = [int(v) for v in torch.randint(1, 13, (n,), generator=g)]
+            rows = int(torch.randint(1, 9, (1,), generator=g))
+            every = (1, 2, 4, 7)[trial % 4]
+            nm.lib.rt_debug_tune(1700 + every, 0)
+            got = nm.generate([texts[i] for i in pick], frames, sp_fixed, seed=3, item_ids=[ids[i] for i in pick], max_rows=rows)
+            assert nm.generate_stats()["rows"] == min(rows, n)
+            for i, f, c in zip(pick, frames, got):
+                assert torch.equal(c, full_fixed[i][:f]), (trial, n, rows, every, i)
+            got = nm.generate([texts[i] for i in pick], frames, sp_live, seed=4, item_ids=[ids[i] for i in pick], max_rows=rows,
+                              ignore_eos=False, min_frames=1)
+            for i, f, c in zip(pick, frames, got):
+                assert torch.equal(c, full_live[i][:f]), (trial, n, rows, every, i, "live")
+    finally:
+        nm.lib.rt_debug_tune(1704, 0)
+        nm.close()
