@@ -220,6 +220,8 @@ def to_native(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str, tor
     out["codec.fin_b"] = f32(state[f"codec.decoder.{n + 1}.conv.bias"])
     # ---- conditioning front-end (every conv, strided ones included, is [Co][k*Ci] with column = tap*Ci + ci: a k = 2r, stride r
     # conv over [T][Ci] is the 2-tap conv over the clip viewed as [T/r][r*Ci], whose column order is the same)
+    if c.enc_filters <= 0:            # a checkpoint without the conditioning front-end (weights.load_safetensors)
+        return out
     out["enc.conv0_w"] = f32(state["enc.conv.0.weight"][:, 0, :]).reshape(-1)
     out["enc.conv0_b"] = f32(state["enc.conv.0.bias"])
     for i in range(1, 2 + 3 * len(c.enc_ratios)):

@@ -105,7 +105,11 @@ class ModelConfig:
     text_hidden: int = 2048
     n_groups: int = 16
     sample_rate: int = 24000
-    max_positions: int = 4096
+    max_positions: int = 4096        # KV rows per sequence the engine allocates (prompt + frames): sized by this package, NOT by a checkpoint
+    # ``max_position_embeddings`` of a checkpoint's config.json, if it has one.  The reference uses it for ONE thing: refining
+    # the segment character limit (providers/qwen.py:131-139) - and that is all it feeds here (provider._max_model_chars).  It
+    # must never size the KV caches: 32768 positions x 33 slots of the 1.7B talker would be 124 GB.
+    hf_max_position_embeddings: int = 0
     # text-side control ids
     tts_pad_id: int = 151671
     tts_bos_id: int = 151672
@@ -254,7 +258,8 @@ def from_hf_config(js: dict, name: str = "hf") -> ModelConfig:
     if "codec_eos_token_id" in t:
         cfg.codec_eos_id = t["codec_eos_token_id"]
     if "max_position_embeddings" in t.get("text_config", t):       # the reference refines its segment limit from it (qwen.py:131-139)
-        cfg.max_positions = int(t.get("text_config", t)["max_position_embeddings"])
+        cfg.hf_max_position_embeddings = int(t.get("text_config", t)["max_position_embeddings"])
+        cfg.max_positions = min(cfg.max_positions, cfg.hf_max_position_embeddings)      # (a model trained on fewer positions than the default allocation)
     c2w = js.get("code2wav_config", js.get("speech_tokenizer_config", {}))
     if c2w:
         d = cfg.codec

@@ -67,7 +67,7 @@ __global__ void k_pack_weight16(const bf16_t* __restrict__ src, int N, int K, in
 template <int MT>
 __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t* __restrict__ A, int M, int K, const bf16_t* __restrict__ Wp,
                                                      int NT, int KT, int kt_per_split, float* __restrict__ out, int64_t ldc,
-                                                     int N) {
+                                                     int N, int64_t slab_stride) {
     const int lane = threadIdx.x & 63;
     const int nt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (nt >= NT) return;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const bf16_t* __restrict__ 
             acc[mt] = mfma32(a, b, acc[mt]);
         }
     }
-    float* o = out + (int64_t)blockIdx.y * M * ldc;
+    float* o = out + (int64_t)blockIdx.y * slab_stride;
     const int n = nt * 32 + r;
     if (n < N) {
 #pragma unroll
@@ -888,18 +888,22 @@ int skinny_pick_split(int M, int N, int K, int n_cu) {
     const int tiles = (N + 31) / 32, KT = (K + 15) / 16;
     const int target = n_cu * g_skinny_waves_per_cu;
     int s = 1;
-    while (s < 32 && tiles * (s * 2) <= target && KT % (s * 2) == 0 && KT / (s * 2) >= 4) s *= 2;
+    // (a K segment is a whole number of the prompt-prefill kernel's 64-deep steps whenever K allows it: k_gemm_mid adds K in
+    // these very segments, so that a prompt row gets the same float32 sums from either kernel - 0.6B down-projection, K = 3072:
+    // 16 segments of 12 k-tiles, not 32 of 6)
+    while (s < 32 && tiles * (s * 2) <= target && KT % (s * 2) == 0 && KT / (s * 2) >= 4 && (KT % 4 != 0 || (KT / (s * 2)) % 4 == 0)) s *= 2;
     return s;
 }
 
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
-                       hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       hipEvent_t ev_start, hipEvent_t ev_stop, int64_t slab_stride) {
+    if (slab_stride <= 0) slab_stride = (int64_t)M * ldc;
     if (M < 1 || M > 64) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: M=%d outside 1..64", M);
     if (w.K != w.Kp) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: K=%d must be a multiple of 16", w.K);
     const int NT = w.Np / 32, KT = w.Kp / 16;
     if (split_k < 1 || KT % split_k) return rt_fail(ctx, RT_ERR_INVALID, "gemm_skinny: split_k=%d does not divide %d k-tiles", split_k, KT);
     dim3 grid((NT + 3) / 4, split_k);
-    if (g_skinny_variant > 0 && (ev_start || ev_stop)) {
+    if (g_skinny_variant > 0 && (ev_start || ev_stop) && slab_stride == (int64_t)M * ldc) {
         const int mt = M <= 32 ? 1 : 2;
         const size_t lds = (size_t)mt * 32 * ((KT / split_k) * 32 + 16);
         if (lds <= 64 * 1024) {
@@ -916,26 +920,31 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
     }
     // hipExtLaunchKernelGGL stamps the events at the kernel's own begin/end on the device (no launch gaps inside)
     if (!ev_start && !ev_stop) {
-        if (M <= 32) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
-        else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N);
+        if (M <= 32) hipLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N, slab_stride);
+        else hipLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, d_a, M, w.K, w.data, NT, KT, KT / split_k, d_out, ldc, w.N, slab_stride);
     } else if (M <= 32)
         hipExtLaunchKernelGGL(k_gemm_skinny<1>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
-                              KT / split_k, d_out, ldc, w.N);
+                              KT / split_k, d_out, ldc, w.N, slab_stride);
     else
         hipExtLaunchKernelGGL(k_gemm_skinny<2>, grid, dim3(256), 0, ctx->stream, ev_start, ev_stop, 0, d_a, M, w.K, w.data, NT, KT,
-                              KT / split_k, d_out, ldc, w.N);
+                              KT / split_k, d_out, ldc, w.N, slab_stride);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 
 int g_prefill_mid = 1;           // 1: prompt prefills of 65..1024 rows run their GEMMs on k_gemm_mid (no split-K slabs); 2 / 3 force its 64 / 128 tiles
-bool gemm_mid_ok(int M, const PackedW& w) { return g_prefill_mid && M > 64 && M <= 1024 && w.K % MID_BK == 0 && w.K >= 128 && w.Kp == w.K; }
+bool gemm_mid_shape_ok(const PackedW& w) { return g_prefill_mid && w.K % MID_BK == 0 && w.K >= 128 && w.Kp == w.K; }
+bool gemm_mid_ok(int M, const PackedW& w) { return gemm_mid_shape_ok(w) && M > 64 && M <= 1024; }
 int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc) {
     if (!gemm_mid_ok(M, w)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_mid: M=%d K=%d outside its range", M, w.K);
     MidArgs g{A, w.data, out, M, w.N, w.K, w.Np / 32, w.Kp / 16, ldc, 0};
     // same association of the K sum as the skinny kernel's slabs (its split depends on N and K only): see the kernel
     const int S = skinny_pick_split(M, w.N, w.K, ctx->n_cu);
-    if (S > 1 && (g.KT / S) % (MID_BK / 16) == 0) g.seg_it = (g.KT / S) / (MID_BK / 16);
+    if (S > 1) {
+        // (skinny_pick_split only returns such splits for K % 64 == 0; anything else would silently break the batch invariance)
+        if ((g.KT / S) % (MID_BK / 16)) return rt_fail(ctx, RT_ERR_STATE, "gemm_mid: K segments of %d k-tiles are not whole 64-deep steps (K=%d, split %d)", g.KT / S, w.K, S);
+        g.seg_it = (g.KT / S) / (MID_BK / 16);
+    }
     // 128 x 64 tiles (3/4 of the cache-to-CU traffic of 64 x 64) only where they still give >= 3 workgroups per CU - the
     // gate/up projection; with fewer, a bigger tile cannot overlap its LDS phase with its MFMA phase (128 x 128 tiles at M = 460:
     // 25-42 us on the 64-128 workgroups of the narrow projections against 21-23 us for 64 x 64, 42.7 us on gate/up - but with the

@@ -72,10 +72,11 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
 // prompt-prefill GEMM (65..1024 rows): out[M][N] f32 = A[M][K] bf16 . W^T, whole K per 64 x 64 tile, final sums (no slabs)
 extern int g_prefill_mid;
 bool gemm_mid_ok(int M, const PackedW& w);
+bool gemm_mid_shape_ok(const PackedW& w);     // the weight's shape alone (any row count can then be served in chunks of <= 1024 rows)
 int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc);
 // Weight-streaming form for M <= 64 rows (decode): plain bf16 A [M][K], raw f32 slabs out.
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
-                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int64_t slab_stride = 0);   // slab s at d_out + s * slab_stride (0: M * ldc)
 int skinny_pick_split(int M, int N, int K, int n_cu);
 extern int g_decode_col;
 extern int g_use_graph;

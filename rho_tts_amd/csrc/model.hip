@@ -328,18 +328,28 @@ int gemm_rows(rt_model* m, const bf16_t* A, int rows, const PackedW& W, float* s
         prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
         RT_TRY(launch_gemm_skinny(m->ctx, A, rows, W, slabs, W.N, S, e0, e1));
         *n_slabs = S;
-    } else if (gemm_mid_ok(rows, W)) {
-        RT_TRY(launch_gemm_mid(m->ctx, A, rows, W, slabs, W.N));   // prompt prefill: final sums from 64 x 64 tiles over the whole K
+    } else if (gemm_mid_shape_ok(W)) {
+        // prompt prefill: final sums from 64 x 64 tiles over the whole K, K added in the skinny kernel's segments - a row gets the
+        // same float32 sums among 13 rows (skinny) as among 416 or 3000: more than 1024 rows go down in equal chunks of <= 1024
+        // (32 rows x > 30-token texts; the split-K tiled kernel's association would depend on the row count)
+        const int n_chunks = (rows + 1023) / 1024, per = (rows + n_chunks - 1) / n_chunks;
+        for (int r0 = 0; r0 < rows; r0 += per) {
+            const int rc = std::min(per, rows - r0);
+            if (rc > 64) RT_TRY(launch_gemm_mid(m->ctx, A + (size_t)r0 * W.K, rc, W, slabs + (size_t)r0 * W.N, W.N));
+            else {      // (a tail of <= 64 rows cannot occur with equal chunks of > 512 rows; kept for safety: skinny slabs summed here would differ)
+                return rt_fail(m->ctx, RT_ERR_STATE, "gemm_rows: %d-row chunk of a %d-row prefill", rc, rows);
+            }
+        }
         *n_slabs = 1;
     } else {
-        // prefill: a few hundred rows give only a handful of 128x128 tiles; split K until the grid covers the chip
-        const int tiles = ((rows + 127) / 128) * ((W.N + 127) / 128);
-        int S = 1;
-        // (each workgroup's K loop is a chain of ~1-us load round trips, so the grid should be ~3 workgroups per CU deep)
-        while (S < 8 && tiles * S < g_prefill_fill * m->ctx->n_cu && W.K / (S * 2) >= 256) S *= 2;
-        GemmA a; a.ptr = A; a.is_f32 = 0; a.M = rows; a.Cin = W.K; a.taps = 1;
-        GemmEpi e; e.out_f32 = slabs; e.ldc = W.N; e.split_k = S;
-        RT_TRY(launch_gemm(m->ctx, a, W, e));
+        // shapes the prompt-prefill kernel does not take (K % 64 != 0 or K < 128: no preset, the tiny test models): 64-row
+        // blocks on the skinny kernel, whose split depends on the weight's shape only - slower than a tiled GEMM, but a row's
+        // sums must not depend on how many rows it is prefilled with
+        const int S = skinny_pick_split(rows, W.N, W.K, m->ctx->n_cu);
+        for (int r0 = 0; r0 < rows; r0 += 64) {
+            const int rc = std::min(64, rows - r0);
+            RT_TRY(launch_gemm_skinny(m->ctx, A + (size_t)r0 * W.K, rc, W, slabs + (size_t)r0 * W.N, W.N, S, nullptr, nullptr, (int64_t)rows * W.N));
+        }
         *n_slabs = S;
     }
     return RT_OK;
@@ -370,9 +380,17 @@ struct StackWs {
     bf16_t* ao = nullptr;     // [M][q_dim]
     bf16_t* act = nullptr;    // [M][I]
 };
-size_t slab_floats(const rt_stack_dims& d, int M) {
+size_t slab_floats(const rt_stack_dims& d, int M, int n_cu = 256) {
     const size_t widest = std::max<size_t>((size_t)2 * d.inter, (size_t)(d.heads + 2 * d.kv_heads) * d.head_dim);
-    return std::max<size_t>((size_t)M * widest * (M > 64 ? 8 : 1), (size_t)64 * 32768);
+    size_t need = std::max<size_t>((size_t)M * widest * (M > 64 ? 8 : 1), (size_t)64 * 32768);
+    if (M > 64) {       // gemm_rows on a shape k_gemm_mid does not take: the skinny kernel's slabs for every row
+        const int q = d.heads * d.head_dim, qkv = (d.heads + 2 * d.kv_heads) * d.head_dim;
+        const int shapes[4][2] = {{qkv, d.hidden}, {d.hidden, q}, {2 * d.inter, d.hidden}, {d.hidden, d.inter}};
+        for (auto& s : shapes)
+            if (!(g_prefill_mid && s[1] % 64 == 0 && s[1] >= 128))
+                need = std::max<size_t>(need, (size_t)M * s[0] * skinny_pick_split(M, s[0], s[1], n_cu));
+    }
+    return need;
 }
 int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w, bool precise = false) {
     if (precise) {

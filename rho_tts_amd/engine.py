@@ -78,7 +78,6 @@ class Engine:
         self.device = torch.device(f"cuda:{device_ordinal}")
         self.ctx = _native.Context(device_ordinal)          # raises NativeUnavailable without a gfx950 GPU
         self.max_batch = max_batch
-        self.model = NativeModel(self.ctx, self.cfg, max_batch=max_batch, max_positions=max_positions)
         has_ckpt = has_ckpt and not synthetic
         self.synthetic = not has_ckpt
         self.ignore_eos: Optional[bool] = None              # None: synthetic weights never emit EOS -> fixed lengths; real weights stop at EOS
@@ -87,6 +86,8 @@ class Engine:
                 state = load_safetensors(self.cfg, model_path, device=self.device)
             else:
                 state = synthetic_state(self.cfg, weight_seed, device=self.device)
+            # (created after the load: a checkpoint without audio-encoder tensors has cleared cfg.codec.enc_filters by now)
+            self.model = NativeModel(self.ctx, self.cfg, max_batch=max_batch, max_positions=max_positions)
             self.model.load_state(state)
             del state
             torch.cuda.empty_cache()
@@ -111,6 +112,9 @@ class Engine:
         """The conditioning front-end (the reference re-runs it on every call via ref_audio=path, qwen.py:253-258): the clip is
         encoded ON the GPU - conv encoder, transformer, residual vector quantiser, speaker head (rt_voice_encode) - into the
         reference codec frames and the speaker embedding of the prompt.  A clip may take at most half of the KV rows."""
+        if self.cfg.codec.enc_filters <= 0:
+            raise ValueError("this checkpoint ships no audio encoder (conditioning front-end): voice cloning from reference audio is "
+                             "unavailable - use a built-in speaker, or a checkpoint that includes the speech-tokenizer encoder")
         audio = load_audio(audio_or_path, self.cfg.sample_rate) if isinstance(audio_or_path, str) else np.asarray(audio_or_path, np.float32)
         codes, spk = self.model.encode_voice(audio, max_frames=self.model.max_positions // 2)
         return VoiceConditioning(language, None, spk, self.tokenizer.encode(ref_text), codes)
@@ -174,6 +178,21 @@ class Engine:
         from .dist import bucket_batches
         return bucket_batches(frames, self.max_batch)
 
+    def pick_rows(self, plan: Sequence[int]) -> int:
+        """Decode rows for a work list with estimated lengths ``plan``.  A frame on 33..64 rows costs up to ~1.4x a frame on 32
+        (measured), and a list-scheduled queue on R rows takes about max(longest, sum / R) frames: 32 busy
+        rows with a queue beat 64 half-idle ones only when the lengths are ragged enough - so the narrower schedule is taken
+        only when this model puts it clearly (10 %) ahead; n <= max_batch texts of similar length stay one static batch."""
+        n = len(plan)
+        full = min(n, self.max_batch)
+        if full <= 32 or not plan:
+            return full
+
+        def cost(rows: int) -> float:
+            frames = max(float(max(plan)), float(sum(plan)) / rows)
+            return frames * (1.0 + 0.4 * max(0, rows - 32) / 32.0)
+        return 32 if cost(32) < 0.9 * cost(full) else full
+
     def synthesize(self, texts: Sequence[str], seed: int = 789, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
                    max_frames: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
                    continuous: Optional[bool] = None, plan_frames: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
@@ -193,15 +212,15 @@ class Engine:
             frames = [self.frames_for(t, len(self.tokenizer.encode(t))) for t in texts]
         plan = [int(f) for f in plan_frames] if plan_frames is not None else frames
         wavs: List[Optional[torch.Tensor]] = [None] * n
+        rows = self.pick_rows(plan)
         if continuous is None:
-            # (the column decode path serves <= 64 rows; a 33..95-text queue on a 64-row engine goes to 32 busy rows, see below)
-            continuous = (n > self.max_batch or (self.max_batch > 32 and 32 < n < 96)) and self.max_batch <= 64
-        if continuous and (n > self.max_batch or (self.max_batch > 32 and 32 < n < 96)):
+            continuous = self.max_batch <= 64 and (n > self.max_batch or rows < min(n, self.max_batch))
+        if continuous and self.max_batch > 64:
+            raise ValueError(f"continuous batching decodes on at most 64 rows (engine built with max_batch={self.max_batch})")
+        if continuous and (n > self.max_batch or rows < n):
             order = sorted(range(n), key=lambda i: (-plan[i], i))          # longest first: short items fill the tail of the schedule
-            # a 64-row frame costs ~1.4x a 32-row one: a queue shorter than ~3 x 32 texts is served faster by 32 busy rows
-            rows = 32 if (self.max_batch > 32 and n < 96) else 0
             codes = self.generate_codes([texts[i] for i in order], seed, [ids[i] for i in order], cancel_flag, [frames[i] for i in order],
-                                        max_rows=rows)
+                                        max_rows=rows if rows < min(n, self.max_batch) else 0)
             st = self.model.generate_stats()
             by_len = sorted(range(n), key=lambda j: (-int(codes[j].shape[0]), j))
             for j, w in zip(by_len, self.vocode([codes[j] for j in by_len])):

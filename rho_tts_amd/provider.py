@@ -135,6 +135,8 @@ class BatchedPipeline:
                     if self.max_iterations == 1:
                         state[w]["best"] = a
                         accepted[w] = a
+                        if getattr(self, "auto_sort_good_dir", None) or getattr(self, "auto_sort_bad_dir", None):
+                            self._auto_sort_only(a)          # drift detection for auto-sort even without validation retries (:801-818)
                         continue
                     if self._validate_segment(a, work[w][2], state[w]):
                         accepted[w] = a                      # valid: this attempt's audio is kept (:859)
@@ -246,6 +248,15 @@ class BatchedPipeline:
         except Exception as e:  # noqa: BLE001
             logger.warning(f"    validation error ({e})")
             return False
+
+    def _auto_sort_only(self, audio: torch.Tensor) -> None:
+        """``max_iterations == 1`` with an auto-sort directory set (base_tts.py:801-818): score the accepted audio and copy it to
+        the good / bad folder; nothing is retried and no score reaches the metadata.  As in the reference, only the copy itself
+        is non-fatal (``_auto_sort_audio`` swallows ``OSError``)."""
+        scorer = getattr(self, "drift_scorer", None)
+        with self._validation_input(audio) as path:
+            drift = float(scorer(audio, self.sample_rate)) if scorer is not None else self._validate_accent_drift(path)[0]
+            self._auto_sort_audio(path, drift)
 
     def _validation_input(self, audio: torch.Tensor):
         """What the validators are handed: the reference's file-based validators get a temporary 16-bit WAV
@@ -402,7 +413,10 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
                     self._ctx.close()
                     self._ctx = None
                 self._engine = Engine(self.model_path, self._device_ordinal(), max_batch=max(1, min(64, int(self.batch_size))))
-                self._max_model_chars = min(self.MAX_MODEL_CHARS, self._engine.cfg.max_positions)
+                # the reference refines the limit from the checkpoint's max_position_embeddings (qwen.py:131-139); a checkpoint
+                # without one keeps MAX_MODEL_CHARS.  (The KV allocation - cfg.max_positions - is a separate number.)
+                hf_pos = int(getattr(self._engine.cfg, "hf_max_position_embeddings", 0) or 0)
+                self._max_model_chars = min(self.MAX_MODEL_CHARS, hf_pos) if hf_pos > 0 else self.MAX_MODEL_CHARS
             return self._engine
 
     def _ensure_voice(self, eng) -> None:

@@ -1,23 +1,18 @@
-"""Voice-conditioning containers and audio loading, plus a SYNTHETIC code generator for decode-path tests.
+"""Voice-conditioning container, audio loading and the benchmark's synthetic reference clip.
 
-The product path encodes reference audio on the GPU (``Engine.conditioning_from_audio`` -> ``rt_voice_encode``: conv encoder,
-transformer, residual vector quantiser, speaker head; reference call site providers/qwen.py:253-258).  ``conditioning_from_audio``
-below is NOT that: it derives a deterministic prompt of the right SHAPE from block energies (one frame of ``n_groups`` codes per
-1920 samples, a hashed embedding) without running any model, and is kept only so that decode-path parity tests and the CPU
-oracle can be driven by a voice prompt that does not depend on the encoder under test (tests/test_model_shapes_gpu.py).
+Reference audio is encoded on the GPU (``Engine.conditioning_from_audio`` -> ``rt_voice_encode``: conv encoder, transformer,
+residual vector quantiser, speaker head; reference call site providers/qwen.py:253-258).  Nothing in this package fabricates
+conditioning: the stand-in prompt generator some decode-path tests use lives with them (tests/fake_voice.py).
 """
 from __future__ import annotations
 
 import wave
-import zlib
 from dataclasses import dataclass
 from typing import List, Optional
 
 import numpy as np
 import torch
 
-from .config import ModelConfig
-from .weights import hash_uniform
 
 
 @dataclass
@@ -52,28 +47,6 @@ def load_audio(path: str, target_sr: int) -> np.ndarray:
         pos = np.arange(int(round(x.size * target_sr / sr)), dtype=np.float64) * (sr / target_sr)
         x = np.interp(pos, np.arange(x.size, dtype=np.float64), x).astype(np.float32)
     return np.ascontiguousarray(x, dtype=np.float32)
-
-
-def conditioning_from_audio(cfg: ModelConfig, audio: np.ndarray, ref_text_ids: List[int], language: str = "english",
-                            max_frames: Optional[int] = None) -> VoiceConditioning:
-    hop, G, cb = cfg.codec.total_upsample, cfg.n_groups, cfg.codec.codebook_size
-    x = np.asarray(audio, dtype=np.float32).reshape(-1)
-    T = x.size // hop
-    if max_frames is not None:
-        T = min(T, max_frames)
-    if T < 1:
-        raise ValueError("reference audio is shorter than one codec frame")
-    fr = x[: T * hop].reshape(T, hop)
-    sub = hop // G
-    blocks = fr[:, : sub * G].reshape(T, G, sub).astype(np.float64)
-    e = np.log10((blocks ** 2).mean(axis=2) + 1e-10)                               # [T, G] in about [-10, 0]
-    zc = (np.diff(np.signbit(blocks), axis=2) != 0).mean(axis=2)                   # [T, G] zero-crossing rate
-    q = np.clip((e + 8.0) / 8.0, 0.0, 1.0) * 0.75 + np.clip(zc * 4.0, 0.0, 1.0) * 0.25
-    codes = np.minimum((q * cb).astype(np.int64), cb - 1)
-    stats = np.round(np.concatenate([e.mean(axis=0), zc.mean(axis=0), [float(T)]]) * 64).astype(np.int64)
-    seed = zlib.crc32(stats.tobytes()) | (0x5EA7 << 32)
-    emb = next(hash_uniform(cfg.talker.hidden, seed))[1] * (0.05 * 12 ** 0.5)
-    return VoiceConditioning(language, None, emb.to(torch.float32), list(ref_text_ids), torch.from_numpy(codes))
 
 
 def synthetic_reference_clip(seconds: float = 30.0, sr: int = 24000, seed: int = 789) -> np.ndarray:

@@ -105,7 +105,8 @@ def tensor_specs(cfg: ModelConfig) -> List[Spec]:
     n = len(c.upsample_rates) + 1
     s += [(f"codec.decoder.{n}.alpha", (ch[-1],), "bias", 0.3), (f"codec.decoder.{n}.beta", (ch[-1],), "bias", 0.3),
           (f"codec.decoder.{n + 1}.conv.weight", (1, ch[-1], 7), "fan", 0.1), (f"codec.decoder.{n + 1}.conv.bias", (1,), "bias", 0.0)]
-    s += encoder_specs(cfg)
+    if c.enc_filters > 0:            # the conditioning front-end is optional: CustomVoice checkpoints ship none (enc_filters = 0)
+        s += encoder_specs(cfg)
     return s
 
 
@@ -235,7 +236,20 @@ _HF_RULES = [
     (r"^talker\.code_predictor\.lm_head\.", "predictor.lm_head."),
     (r"^talker\.code_predictor\.(small_to_mtp_projection|mtp_proj)\.", "predictor.mtp_proj."),
     (r"^(code2wav|speech_tokenizer\.decoder)\.", "codec."),
+    # conditioning front-end: this package's own names under a speech-tokenizer prefix, and the layout of the Mimi codec in the
+    # container's transformers (models/mimi/modeling_mimi.py: encoder.layers.N.conv, encoder_transformer.layers.N, downsample.conv,
+    # quantizer.{semantic,acoustic}_residual_vector_quantizer) - UNVERIFIED for Qwen3-TTS like everything else here
+    (r"^speech_tokenizer\.(encoder\.)?enc\.", "enc."),
+    (r"^speech_tokenizer\.encoder_transformer\.(layers\.\d+\.|norm\.)", r"enc.transformer.\1"),
+    (r"^speech_tokenizer\.downsample\.conv\.", "enc.downsample."),
+    (r"^speech_tokenizer\.quantizer\.semantic_residual_vector_quantizer\.input_proj\.", "enc.vq.semantic.input_proj."),
+    (r"^speech_tokenizer\.quantizer\.acoustic_residual_vector_quantizer\.input_proj\.", "enc.vq.acoustic.input_proj."),
+    (r"^speech_tokenizer\.speaker_encoder\.", "enc.spk."),
 ]
+
+# Slots the kernels consume as float32 (nearest-neighbour search of the quantiser, speaker head): a float32 checkpoint tensor
+# stays float32 for them - rounding a codebook to bf16 first can move a code decision.
+_F32_SLOTS = ("enc.vq.codebook.", "enc.spk.")
 
 
 def remap_name(name: str) -> str:
@@ -263,11 +277,12 @@ def load_safetensors(cfg: ModelConfig, model_dir: str, device="cpu") -> Dict[str
     nothing is executed from the files."""
     from safetensors import safe_open
 
-    want = {sp[0]: sp[1] for sp in tensor_specs(cfg)}
-    state: Dict[str, torch.Tensor] = {}
     files = checkpoint_files(model_dir)
     if not files:
         raise FileNotFoundError(f"no .safetensors files in {model_dir}")
+    want = {sp[0]: sp[1] for sp in tensor_specs(cfg)}
+    enc_names = {sp[0] for sp in encoder_specs(cfg)} if cfg.codec.enc_filters > 0 else set()
+    state: Dict[str, torch.Tensor] = {}
     unknown: List[str] = []
     for path in files:
         sub = os.path.relpath(os.path.dirname(path), model_dir)
@@ -280,9 +295,16 @@ def load_safetensors(cfg: ModelConfig, model_dir: str, device="cpu") -> Dict[str
                     tns = sf.get_tensor(k)
                     if tuple(tns.shape) != tuple(want[name]):
                         raise ValueError(f"{k}: checkpoint shape {tuple(tns.shape)} != configured {want[name]}")
-                    state[name] = tns.to(torch.bfloat16)
+                    keep_f32 = tns.dtype == torch.float32 and name.startswith(_F32_SLOTS)
+                    state[name] = tns if keep_f32 else tns.to(torch.bfloat16)
                 else:
                     unknown.append(k)
+    if enc_names and not (enc_names & set(state)):
+        # no encoder tensors at all: a checkpoint without the conditioning front-end (CustomVoice models never use it).  The
+        # model is built without one - rt_voice_encode then answers RT_ERR_UNSUPPORTED, as include/rho_tts_amd.h documents.
+        cfg.codec.enc_filters = 0
+        for k in enc_names:
+            want.pop(k, None)
     missing = sorted(set(want) - set(state))
     if missing:
         raise ValueError(f"checkpoint is missing {len(missing)} of {len(want)} tensors, e.g. {missing[:4]}"

@@ -308,6 +308,19 @@ def main():
     pipe["validated_retries"] = {"texts": texts, "out": run(t, texts), "calls": list(t.calls), "drift_calls": list(t.drift_calls),
                                  "text_calls": list(t.text_calls)}
 
+    # max_iterations = 1 with an auto-sort directory: drift detection + sorting still run, once per segment, and no score
+    # reaches the metadata (base_tts.py:801-818)
+    t = Fake()
+    t._max_chars_explicit = True
+    t.max_iterations = 1
+    t.auto_sort_good_dir = "/nonexistent/good"
+    install_scripted_validators(t)
+    sorted_calls = []
+    t._auto_sort_audio = lambda path, drift_prob: sorted_calls.append(float(drift_prob))
+    texts = list(VALIDATION_TEXTS)
+    pipe["auto_sort_single_pass"] = {"texts": texts, "out": run(t, texts), "calls": list(t.calls), "drift_calls": list(t.drift_calls),
+                                     "text_calls": list(t.text_calls), "sorted": sorted_calls}
+
     seg_cases = {}
     t = Fake()
     for fs in (True, False):

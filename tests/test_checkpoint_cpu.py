@@ -88,7 +88,15 @@ def test_from_hf_config_reads_a_handwritten_dict():
     assert c.talker.rope_theta == 500000.0 and c.talker.rms_eps == 1e-5
     assert (c.predictor.hidden, c.predictor.layers, c.predictor.head_dim, c.predictor_vocab) == (768, 4, 96, 1024)
     assert (c.codec_vocab, c.n_groups, c.text_vocab, c.text_hidden, c.codec_eos_id, c.codec_pad_id) == (3100, 12, 150000, 1536, 2160, 2161)
-    assert c.max_positions == 8192 and c.has_mtp_proj
+    # max_position_embeddings feeds the segment character limit only; the KV allocation keeps this package's own size
+    assert c.hf_max_position_embeddings == 8192 and c.max_positions == config.qwen3_tts_1p7b().max_positions and c.has_mtp_proj
+    def with_pos(n):
+        t = dict(js["talker_config"])
+        t["text_config"] = dict(t["text_config"], max_position_embeddings=n)
+        return dict(js, talker_config=t)
+    assert config.from_hf_config(with_pos(32768)).max_positions == config.qwen3_tts_1p7b().max_positions   # 32768 x 33 slots would be 124 GB of KV
+    assert config.from_hf_config(with_pos(32768)).hf_max_position_embeddings == 32768
+    assert config.from_hf_config(with_pos(1024)).max_positions == 1024
     assert (c.codec.codebook_size, c.codec.num_quantizers, c.codec.hidden, c.codec.layers, c.codec.upsample_rates) == (1024, 12, 512, 6, (8, 5, 4, 2))
     # a bare dict (no sub-configs) falls back to the preset dimensions
     assert config.from_hf_config({}, name="x").talker.hidden == config.qwen3_tts_1p7b().talker.hidden
@@ -117,3 +125,63 @@ def test_tokenizer_json_is_used_when_the_checkpoint_has_one(tmp_path):
     t = load_tokenizer(str(tmp_path), 512)
     assert isinstance(t, FileTokenizer) and t.encode("hello world.") == [5, 9, 11] and t.encode("hello there") == [5, 0]
     assert isinstance(load_tokenizer("Qwen/none", 512), HashTokenizer)
+
+
+def test_checkpoint_without_audio_encoder_loads(tmp_path):
+    """CustomVoice checkpoints never use the conditioning front-end and ship no encoder: the load must not demand enc.* tensors
+     - the model is then built without an encoder (enc_filters = 0, rt_voice_encode -> RT_ERR_UNSUPPORTED)."""
+    from safetensors.torch import save_file
+    from rho_tts_amd._native_model import rt_config, to_native
+    cfg = config.tiny()
+    state = weights.synthetic_state(cfg, 789)
+    d = str(tmp_path / "no-enc")
+    os.makedirs(d)
+    save_file({k: v for k, v in state.items() if not k.startswith("enc.")}, os.path.join(d, "model.safetensors"))
+    cfg2 = config.tiny()
+    back = weights.load_safetensors(cfg2, d)
+    assert cfg2.codec.enc_filters == 0 and not any(k.startswith("enc.") for k in back)
+    assert set(back) == {sp[0] for sp in weights.tensor_specs(cfg2)}
+    native = to_native(back, cfg2)
+    assert not any(k.startswith("enc.") or k.startswith("etf.") for k in native)
+    assert rt_config(cfg2, 2, 64, 16).enc.filters == 0
+    # a checkpoint with SOME encoder tensors is incomplete, not encoder-less
+    part = {k: v for k, v in state.items() if k != "enc.downsample.weight"}
+    save_file(part, os.path.join(d, "model.safetensors"))
+    with pytest.raises(ValueError, match="missing 1 of"):
+        weights.load_safetensors(config.tiny(), d)
+
+
+def test_float32_codebooks_stay_float32_and_encoder_names_remap(tmp_path):
+    from safetensors.torch import save_file
+    cfg = config.tiny()
+    state = weights.synthetic_state(cfg, 789)
+    g = torch.Generator().manual_seed(1)
+    cb = torch.randn(state["enc.vq.codebook.0"].shape, generator=g) * 0.37          # not bf16-representable
+    assert not torch.equal(cb, cb.to(torch.bfloat16).float())
+
+    def hf(k):
+        if k.startswith("enc.transformer."):
+            return k.replace("enc.transformer.", "speech_tokenizer.encoder_transformer.", 1)
+        if k == "enc.downsample.weight":
+            return "speech_tokenizer.downsample.conv.weight"
+        if k.startswith("enc.vq.semantic.input_proj."):
+            return k.replace("enc.vq.semantic.", "speech_tokenizer.quantizer.semantic_residual_vector_quantizer.", 1)
+        if k.startswith("enc.vq.acoustic.input_proj."):
+            return k.replace("enc.vq.acoustic.", "speech_tokenizer.quantizer.acoustic_residual_vector_quantizer.", 1)
+        if k.startswith("enc.spk."):
+            return k.replace("enc.spk.", "speech_tokenizer.speaker_encoder.", 1)
+        if k.startswith("enc."):
+            return "speech_tokenizer." + k
+        return k
+    d = str(tmp_path / "f32")
+    os.makedirs(d)
+    out = {hf(k): v for k, v in state.items()}
+    out[hf("enc.vq.codebook.0")] = cb
+    out["talker.norm.weight"] = state["talker.norm.weight"].float()                # other float32 tensors still go to bf16
+    save_file(out, os.path.join(d, "model.safetensors"))
+    back = weights.load_safetensors(cfg, d)
+    assert set(back) == set(state)
+    assert back["enc.vq.codebook.0"].dtype == torch.float32 and torch.equal(back["enc.vq.codebook.0"], cb)
+    assert back["talker.norm.weight"].dtype == torch.bfloat16
+    from rho_tts_amd._native_model import to_native
+    assert torch.equal(to_native(back, cfg)["enc.cbT0"].reshape(cb.shape[1], cb.shape[0]).t(), cb)

@@ -47,7 +47,8 @@ def ctx():
 
 
 def clone_voice(cfg, tok, seconds=30.0):
-    from rho_tts_amd.voice import conditioning_from_audio, synthetic_reference_clip
+    from rho_tts_amd.voice import synthetic_reference_clip
+    from tests.fake_voice import conditioning_from_audio
     clip = synthetic_reference_clip(seconds, cfg.sample_rate, 789)
     ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(75))
     return conditioning_from_audio(cfg, clip, tok.encode(ref_text), "english", max_frames=cfg.max_positions // 2)

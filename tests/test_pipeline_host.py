@@ -324,6 +324,29 @@ def test_validation_retries_keep_the_references_scores(golden_pipe, bs):
         assert t.calls.count(text) == c["calls"].count(text)
 
 
+@pytest.mark.parametrize("bs", [1, 2, 32])
+def test_auto_sort_runs_without_validation_retries(golden_pipe, bs):
+    """max_iterations = 1 with an auto-sort directory (base_tts.py:801-818): every accepted segment is scored once and handed
+    to _auto_sort_audio, nothing is retried, no text match runs and no score reaches the metadata - as the reference does."""
+    c = golden_pipe["auto_sort_single_pass"]
+    t = Fake(batch_size=bs); t._max_chars_explicit = True
+    t.max_iterations = 1
+    t.auto_sort_good_dir = "/nonexistent/good"
+    install_scripted_validators(t)
+    sorted_calls = []
+    t._auto_sort_audio = lambda path, drift_prob: sorted_calls.append(float(drift_prob))
+    got = run_with_scores(t, c["texts"])
+    same(got, c["out"])
+    assert all(g["meta_keys"] == ["decay_ratio"] for g in got)
+    assert sorted(map(tuple, t.drift_calls)) == sorted(map(tuple, c["drift_calls"])) and t.text_calls == c["text_calls"] == []
+    assert sorted(sorted_calls) == sorted(c["sorted"]) and t.calls == c["calls"]
+    # without an auto-sort directory no validator is touched at all
+    t2 = Fake(batch_size=bs); t2._max_chars_explicit = True
+    install_scripted_validators(t2)
+    run_with_scores(t2, c["texts"])
+    assert t2.drift_calls == [] and t2.text_calls == []
+
+
 def run_with_scores(tts, texts):
     res = tts._run_pipeline(texts, api.CancellationToken(), None)
     rec = []
