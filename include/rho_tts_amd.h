@@ -36,7 +36,7 @@ extern "C" {
 
 #define RT_API __attribute__((visibility("default")))
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -145,6 +145,23 @@ RT_API int rt_post_process_host(rt_ctx* ctx, const rt_post_params* p, int32_t n_
 
 /* float32 [-1,1] -> int16 PCM with the reference's truncating conversion (base_tts.py:664-666). */
 RT_API int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out);
+
+/* Sub-segment streaming (an EXTENSION - BaseTTS.stream yields whole segments, base_tts.py:1132-1190): the
+ * per-segment leaves of stream() (base_tts.py:1170-1176: _post_process_audio, _trim_silence, _remove_dc_offset, _apply_fades)
+ * for ONE chunk of a segment that is still being decoded.  The two segment-wide quantities are taken from the segment's first
+ * chunk and carried: h_dc_gain[0] = DC offset, h_dc_gain[1] = linear gain to the target RMS (in/out).
+ *   RT_STREAM_MEASURE     first chunk: measure gain (on the raw chunk) and dc (after the trim) and return them; else apply as given
+ *   RT_STREAM_TRIM_START  drop leading silence (first chunk)     RT_STREAM_TRIM_END  drop trailing silence (last chunk)
+ *   RT_STREAM_FADE_IN / _OUT  raised-cosine ramps of p->fade samples at the chunk's start / end (skipped below 2 x fade samples)
+ * y = 0.95 tanh(x gain / 0.95) - dc; the 2-s windowed decay correction needs the whole segment and is not applied.
+ * d_out: capacity n samples; *h_out_len = samples written. */
+#define RT_STREAM_MEASURE    0x01u
+#define RT_STREAM_TRIM_START 0x02u
+#define RT_STREAM_TRIM_END   0x04u
+#define RT_STREAM_FADE_IN    0x08u
+#define RT_STREAM_FADE_OUT   0x10u
+RT_API int rt_stream_chunk(rt_ctx* ctx, const rt_post_params* p, const float* d_in, int64_t n, uint32_t flags, double* h_dc_gain,
+                           float* d_out, int64_t* h_out_len);
 
 /* ------------------------------------------------------------------ model
  * Stands behind the third-party model object the reference drives
@@ -267,6 +284,24 @@ typedef struct rt_generate_args {
 } rt_generate_args;
 
 RT_API int rt_generate(rt_model* m, const rt_generate_args* args);
+/* The same generation in pieces (sub-segment streaming, SURVEY.md 8f-4: BaseTTS.stream, base_tts.py:1132-1190, hands audio over
+ * per segment; here the first codec frames of a segment can be vocoded while the rest is still being decoded).
+ *   rt_generate_begin   validates, prefills the prompts, builds the decode state; args->h_codes / h_n_frames may be NULL; every
+ *                       input array is copied (only h_cancel_flag must stay valid until rt_generate_end).  A run that was
+ *                       begun and never ended is dropped.
+ *   rt_generate_step    runs up to n_frames more frames and returns once the host holds their codes; the next talker step is
+ *                       already in flight on the stream.  *h_frames_run = frames run so far, *h_all_done = every item ended.
+ *   rt_generate_peek    codes of `item` produced so far: frames [first_frame, first_frame + *h_n_frames) into h_codes
+ *                       [max_frames][n_groups]; *h_finished = the item has ended.
+ *   rt_generate_end     writes the results as rt_generate does (either pointer may be NULL) and releases the run; ending a run
+ *                       that has not finished drops it (an error if results were asked for).
+ * Between two steps other calls on the model are allowed (rt_code2wav of the frames already decoded); a voice change is not.
+ * rt_generate == begin + one step of every frame + end: the codes are the same however the frames are cut into steps. */
+RT_API int rt_generate_begin(rt_model* m, const rt_generate_args* args);
+RT_API int rt_generate_step(rt_model* m, int32_t n_frames, int32_t* h_frames_run, int32_t* h_all_done);
+RT_API int rt_generate_peek(rt_model* m, int32_t item, int32_t first_frame, int32_t max_frames, int32_t* h_codes, int32_t* h_n_frames,
+                            int32_t* h_finished);
+RT_API int rt_generate_end(rt_model* m, int32_t* h_codes, int32_t* h_n_frames);
 /* Figures of the last rt_generate: decode frames launched, rows, frames kept over all items (row occupancy =
  * frames_kept / (frames_run * rows)) and the number of row hand-overs to queued items.  Any pointer may be NULL. */
 RT_API int rt_generate_stats(rt_model* m, int64_t* frames_run, int64_t* rows, int64_t* frames_kept, int64_t* hand_overs);
@@ -276,6 +311,41 @@ RT_API int rt_generate_stats(rt_model* m, int64_t* frames_run, int64_t* rows, in
 RT_API int64_t rt_wav_length(rt_model* m, int32_t n_frames);
 RT_API int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_codes, const int32_t* h_n_frames,
                        float* d_wav, int64_t wav_stride, int64_t* h_wav_len);
+
+/* ------------------------------------------------------------------ speech-to-text for validation
+ * Stands behind validation/stt/stt_validator.py:42-148 (_get_whisper_model / transcribe_audio: faster-whisper "tiny" on the CPU,
+ * or transformers' Whisper - :85-107) and the temporary-WAV round trip of base_tts.py:821-830: a generated segment is
+ * transcribed where it already lives, in HBM.  Whisper-shaped encoder-decoder, shape-parametrised:
+ *   PCM (any rate) -> windowed-sinc resampler to `sample_rate` -> log-mel (n_fft-point DFT, hop, n_mels slaney filters, log10,
+ *   (max - 8) floor, (x + 4) / 4; padded to chunk_seconds) -> conv k3 + conv k3 stride 2 (GELU) + positions -> enc_layers pre-LN
+ *   layers -> dec_layers decoder layers (causal self-attention, cross-attention) -> tied LM head -> greedy ids after the forced
+ *   prefix.  Tensor names and layouts: rt_stt_tensor_info; INTEGRATION.md lists them. */
+typedef struct rt_stt rt_stt;
+typedef struct rt_stt_config {
+    int32_t d_model, heads, ffn, enc_layers, dec_layers;
+    int32_t n_mels, n_ctx, n_text_ctx, vocab;          /* n_ctx: encoder positions (1500); n_text_ctx: decoder positions (448) */
+    int32_t n_fft, hop, sample_rate, chunk_seconds;    /* 400, 160, 16000, 30: chunk_seconds * sample_rate / hop == 2 * n_ctx       */
+    int32_t eos_id;
+    int32_t n_prefix, prefix[8];                       /* forced decoder prefix (start-of-transcript, language, task, no-timestamps) */
+    int32_t suppress_from;                             /* ids >= suppress_from are never produced, eos_id excepted (0: none)         */
+    int32_t n_begin_suppress, begin_suppress[4];       /* ids not allowed as the FIRST generated token (space, end-of-sequence)      */
+    int32_t max_new_tokens;
+    int32_t reserved[4];
+} rt_stt_config;
+RT_API int rt_stt_create(rt_ctx* ctx, const rt_stt_config* cfg, rt_stt** out);
+RT_API int rt_stt_destroy(rt_stt* s);
+RT_API int rt_stt_tensor_count(rt_stt* s);
+RT_API int rt_stt_tensor_info(rt_stt* s, int32_t index, char* name, size_t name_cap, int64_t* shape2, int32_t* kind);
+RT_API int rt_stt_set_tensor(rt_stt* s, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols, int32_t on_device);
+RT_API int rt_stt_finalize(rt_stt* s);
+/* d_pcm: mono float32 in HBM at `sample_rate_in` (the TTS output as it stands).  h_tokens receives the ids generated after the
+ * prefix, end-of-sequence excluded (at most max_tokens / cfg.max_new_tokens).  d_first_logits (optional, HBM, [vocab]): the
+ * logits behind the forced prefix, for tests. */
+RT_API int rt_stt_transcribe(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, int32_t* h_tokens, int32_t max_tokens,
+                             int32_t* h_n_tokens, float* d_first_logits);
+/* Stages on their own (tests): the log-mel features [2 n_ctx][n_mels] and the encoder states [n_ctx][d_model], float32 in HBM. */
+RT_API int rt_stt_log_mel(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, float* d_mel);
+RT_API int rt_stt_encode(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, float* d_states);
 
 /* Per-kernel timing of the decode step for bench.py's roofline figure: when enabled, every weight-streaming GEMM
  * launch is bracketed by HIP events on the context's stream. */

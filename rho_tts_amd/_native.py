@@ -19,6 +19,7 @@ RT_OK, RT_ERR_INVALID, RT_ERR_OOM, RT_ERR_LENGTH, RT_ERR_HIP, RT_ERR_CANCELLED, 
 POST_TRIM_START, POST_TRIM_END, POST_DC, POST_FADE_IN, POST_FADE_OUT, POST_JOIN, POST_LOUDNESS, POST_DECAY = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80)
 POST_PIPELINE = 0xFF
+STREAM_MEASURE, STREAM_TRIM_START, STREAM_TRIM_END, STREAM_FADE_IN, STREAM_FADE_OUT = 0x01, 0x02, 0x04, 0x08, 0x10
 
 
 class NativeUnavailable(RuntimeError):
@@ -93,6 +94,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.rt_post_process.argtypes = post_args
     lib.rt_post_process_host.argtypes = post_args
     lib.rt_pcm16.argtypes = [vp, vp, i64, vp]
+    lib.rt_stream_chunk.argtypes = [vp, C.POINTER(PostParams), vp, i64, C.c_uint32, C.POINTER(C.c_double), vp, C.POINTER(i64)]
     from . import _native_model
     _native_model.declare(lib)
 
@@ -209,6 +211,23 @@ class Context:
         rc = fn(self.handle, C.byref(params), n_items, first, ptrs, lens, trim, optrs, ccaps, stats)
         self.check(rc, name)
         return [o[: stats[i].out_len] for i, o in enumerate(outs)], [stats[i] for i in range(n_items)]
+
+    def stream_chunk(self, params: PostParams, x, state, first: bool, last: bool):
+        """rt_stream_chunk: the per-segment leaves for one chunk of a segment still being decoded.  ``state`` is the segment's
+        ``[dc, gain]`` list: written by the first chunk, applied by the later ones.  Returns the processed chunk (GPU tensor)."""
+        import torch
+        x = x.detach().reshape(-1).to(torch.float32).contiguous()
+        if not x.is_cuda:
+            raise ValueError("stream_chunk expects a GPU tensor")
+        flags = (STREAM_MEASURE | STREAM_TRIM_START | STREAM_FADE_IN if first else 0) | (STREAM_TRIM_END | STREAM_FADE_OUT if last else 0)
+        out = torch.empty(max(1, x.numel()), dtype=torch.float32, device=x.device)
+        st = (C.c_double * 2)(float(state[0]), float(state[1]))
+        n_out = C.c_int64()
+        torch.cuda.current_stream(x.device).synchronize()
+        self.check(self.lib.rt_stream_chunk(self.handle, C.byref(params), C.c_void_p(x.data_ptr() if x.numel() else 0), x.numel(), flags, st,
+                                            C.c_void_p(out.data_ptr()), C.byref(n_out)), "rt_stream_chunk")
+        state[0], state[1] = float(st[0]), float(st[1])
+        return out[: n_out.value]
 
     def pcm16(self, x):
         import torch

@@ -69,6 +69,10 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_voice_import.argtypes = [vp, i32, vp, i64]
     lib.rt_generate.argtypes = [vp, C.POINTER(RtGenerateArgs)]
     lib.rt_generate_stats.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
+    lib.rt_generate_begin.argtypes = [vp, C.POINTER(RtGenerateArgs)]
+    lib.rt_generate_step.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.rt_generate_peek.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.rt_generate_end.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.rt_wav_length.restype = i64
     lib.rt_wav_length.argtypes = [vp, i32]
     lib.rt_code2wav.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, i64, C.POINTER(i64)]
@@ -406,11 +410,10 @@ class NativeModel:
         self.ctx.check(self.lib.rt_voice_import(self.handle, prefix_len, C.c_void_p(blob.data_ptr()), blob.numel() * 2), "rt_voice_import")
 
     # ------------------------------------------------------------------ decode
-    def generate(self, texts: Sequence[Sequence[int]], max_frames: Sequence[int], talker=None, predictor=None, seed: int = 789,
-                 item_ids: Optional[Sequence[int]] = None, ignore_eos: bool = True, min_frames: int = 2,
-                 forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: bool = False, cancel_flag=None, max_rows: int = 0):
+    def _generate_args(self, texts, max_frames, talker, predictor, seed, item_ids, ignore_eos, min_frames, forced_codes, cancel_flag, max_rows):
+        """rt_generate_args for a list of token-id lists; returns (args, objects that must stay alive while the call runs)."""
         c = self.cfg
-        B, G = len(texts), c.n_groups
+        B = len(texts)
         talker = talker or RtSampling(0, 0.9, 50, 1.0, 1.0)
         predictor = predictor or talker
         flat = [int(t) for tx in texts for t in tx]
@@ -429,7 +432,7 @@ class NativeModel:
         a.ignore_eos, a.min_frames = int(ignore_eos), min_frames
         a.max_rows = int(max_rows)
         a.tts_eos_id, a.tts_pad_id, a.codec_pad_id, a.codec_bos_id = c.tts_eos_id, c.tts_pad_id, c.codec_pad_id, c.codec_bos_id
-        keep = []
+        keep = [ids]
         if forced_codes is not None:
             fo = [0]
             ff = []
@@ -442,6 +445,15 @@ class NativeModel:
             keep.append(fa)
         if cancel_flag is not None:
             a.h_cancel_flag = C.pointer(cancel_flag)          # a ctypes.c_int32 another thread may set to 1
+            keep.append(cancel_flag)
+        return a, keep
+
+    def generate(self, texts: Sequence[Sequence[int]], max_frames: Sequence[int], talker=None, predictor=None, seed: int = 789,
+                 item_ids: Optional[Sequence[int]] = None, ignore_eos: bool = True, min_frames: int = 2,
+                 forced_codes: Optional[Sequence[torch.Tensor]] = None, trace: bool = False, cancel_flag=None, max_rows: int = 0):
+        c = self.cfg
+        B, G = len(texts), c.n_groups
+        a, keep = self._generate_args(texts, max_frames, talker, predictor, seed, item_ids, ignore_eos, min_frames, forced_codes, cancel_flag, max_rows)
         tot = sum(int(v) for v in max_frames)
         codes = (C.c_int32 * (tot * G))()
         nfr = (C.c_int32 * B)()
@@ -464,6 +476,48 @@ class NativeModel:
             out.append(flat_codes[off: off + nfr[b]].clone())
             off += int(max_frames[b])
         return (out, tr) if trace else out
+
+    # ---- the same generation in pieces (rt_generate_begin / _step / _peek / _end): sub-segment streaming
+    def generate_begin(self, texts, max_frames, talker=None, predictor=None, seed: int = 789, item_ids=None, ignore_eos: bool = True,
+                       min_frames: int = 2, cancel_flag=None, max_rows: int = 0) -> None:
+        a, keep = self._generate_args(texts, max_frames, talker, predictor, seed, item_ids, ignore_eos, min_frames, None, cancel_flag, max_rows)
+        self._run_keep = (keep, [int(v) for v in max_frames])
+        self.ctx.check(self.lib.rt_generate_begin(self.handle, C.byref(a)), "rt_generate_begin")
+
+    def generate_step(self, n_frames: int):
+        """Run up to ``n_frames`` more frames; returns (frames run so far, every item has ended)."""
+        run, done = C.c_int32(), C.c_int32()
+        self.ctx.check(self.lib.rt_generate_step(self.handle, int(n_frames), C.byref(run), C.byref(done)), "rt_generate_step")
+        return int(run.value), bool(done.value)
+
+    def generate_peek(self, item: int, first_frame: int, max_frames: int):
+        """Codes of ``item`` decoded so far from ``first_frame`` on: (int64 tensor [n, n_groups], the item has ended)."""
+        import numpy as np
+        G = self.cfg.n_groups
+        buf = (C.c_int32 * max(1, int(max_frames) * G))()
+        n, fin = C.c_int32(), C.c_int32()
+        self.ctx.check(self.lib.rt_generate_peek(self.handle, int(item), int(first_frame), int(max_frames), buf, C.byref(n), C.byref(fin)), "rt_generate_peek")
+        codes = torch.from_numpy(np.frombuffer(buf, dtype=np.int32)[: n.value * G].astype(np.int64)).reshape(n.value, G)
+        return codes, bool(fin.value)
+
+    def generate_end(self, collect: bool = False):
+        """Release the generation in flight.  ``collect``: return every item's codes as ``generate`` does (needs a finished run)."""
+        keep, max_frames = getattr(self, "_run_keep", (None, []))
+        self._run_keep = None
+        if not collect:
+            self.ctx.check(self.lib.rt_generate_end(self.handle, None, None), "rt_generate_end")
+            return None
+        import numpy as np
+        G, B, tot = self.cfg.n_groups, len(max_frames), sum(max_frames)
+        codes = (C.c_int32 * max(1, tot * G))()
+        nfr = (C.c_int32 * max(1, B))()
+        self.ctx.check(self.lib.rt_generate_end(self.handle, codes, nfr), "rt_generate_end")
+        flat = torch.from_numpy(np.frombuffer(codes, dtype=np.int32).astype(np.int64)).reshape(-1, G)
+        out, off = [], 0
+        for b in range(B):
+            out.append(flat[off: off + nfr[b]].clone())
+            off += max_frames[b]
+        return out
 
     def generate_stats(self) -> dict:
         """Figures of the last ``generate``: decode frames launched, rows, frames kept, row hand-overs to queued items."""

@@ -16,6 +16,8 @@
 
 #pragma clang fp contract(off)
 
+#define RT_TRY_POST(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
 namespace {
 
 constexpr int kThreads = 1024;
@@ -396,6 +398,77 @@ __global__ void k_pcm16(const float* __restrict__ in, int64_t n, int16_t* __rest
     }
 }
 
+
+// ---- sub-segment streaming: the segment-level leaves for ONE chunk of a segment that is still being decoded (an extension -
+// the reference's stream() yields whole segments, base_tts.py:1132-1190 - in the ORDER the reference applies them per segment,
+// base_tts.py:1170-1176: loudness (global gain to the target RMS + tanh soft clip, qwen.py:296-310), silence trim, DC removal,
+// fades), with the two segment-wide quantities carried from the segment's first chunk instead of being measured on audio that
+// does not exist yet:
+//   gain  MEASURED on the first chunk (target RMS / RMS of the raw chunk), applied unchanged to the later ones - no gain step
+//         at a chunk boundary; the 2-s windowed decay correction needs the whole segment and is not part of streaming
+//   dc    MEASURED on the first chunk after its trim, subtracted from every chunk
+// Leading silence is trimmed from the first chunk, trailing silence from the last; fade-in / fade-out only at those two edges.
+// One 1024-thread workgroup per chunk, float64 reductions; frame energies (10-ms windows, hop 5 ms, count_include_pad as
+// avg_pool1d: base_tts.py:366-377) in float64.
+struct StreamState { double dc, gain; int64_t out_len, start; };
+__device__ __forceinline__ float stream_y(const float* x, int64_t i, float gain, float amp) { return amp * tanhf(__fdiv_rn(__fmul_rn(x[i], gain), amp)); }
+__global__ __launch_bounds__(kThreads) void k_stream_chunk(rt_post_params P, const float* __restrict__ x, int64_t n, uint32_t flags, StreamState* st,
+                                                           float* __restrict__ out) {
+    __shared__ double sh_red[kWaves];
+    __shared__ long long sh_first, sh_last;
+    double gain_d = st->gain, dc_d = st->dc;
+    const float amp = (float)P.max_amplitude;
+    if (flags & RT_STREAM_MEASURE) {
+        const double ss = block_sum(sumsq_range(x, 0, n), sh_red);
+        const double rms = sqrt(ss / (double)(n > 0 ? n : 1));
+        gain_d = rms > 1e-8 ? pow(10.0, (P.target_rms_db - 20.0 * log10(rms)) / 20.0) : 1.0;
+    }
+    const float gain = (float)gain_d;
+    // trim bounds on the loudness-corrected chunk
+    int64_t lo = 0, hi = n;
+    if ((flags & (RT_STREAM_TRIM_START | RT_STREAM_TRIM_END)) && P.trim_enabled && n > 0) {
+        const int W = P.window, hop = W / 2;
+        const int64_t n_frames = n / hop + 1;
+        const double thr2 = (double)P.silence_threshold * (double)P.silence_threshold;
+        if (threadIdx.x == 0) { sh_first = n_frames; sh_last = -1; }
+        __syncthreads();
+        long long my_first = n_frames, my_last = -1;
+        for (int64_t f = threadIdx.x; f < n_frames; f += kThreads) {
+            int64_t a = f * hop - W / 2, b = a + W;
+            if (a < 0) a = 0;
+            if (b > n) b = n;
+            double acc = 0.0;
+            for (int64_t i = a; i < b; ++i) { const double v = (double)stream_y(x, i, gain, amp); acc += v * v; }
+            if (acc / (double)W > thr2) { if (f < my_first) my_first = f; if (f > my_last) my_last = f; }
+        }
+        atomicMin(&sh_first, my_first);
+        atomicMax(&sh_last, my_last);
+        __syncthreads();
+        if (sh_last < 0) { lo = 0; hi = n < W ? n : W; }            // all silent: a window's worth stays (base_tts.py:379-380)
+        else {
+            if (flags & RT_STREAM_TRIM_START) lo = (int64_t)sh_first * hop;
+            if (flags & RT_STREAM_TRIM_END) { hi = ((int64_t)sh_last + 2) * hop; if (hi > n) hi = n; }
+            if (lo > hi) lo = hi;
+        }
+    }
+    const int64_t m = hi - lo;
+    if (flags & RT_STREAM_MEASURE) {
+        double acc = 0.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += (double)stream_y(x, i, gain, amp);
+        dc_d = m > 0 ? block_sum(acc, sh_red) / (double)m : 0.0;
+    }
+    const float dc = (float)dc_d;
+    const int F = P.fade;
+    const bool fades = m >= 2 * (int64_t)F && F > 0;
+    for (int64_t i = threadIdx.x; i < m; i += kThreads) {
+        float v = __fsub_rn(stream_y(x, lo + i, gain, amp), dc);
+        if (fades && (flags & RT_STREAM_FADE_IN) && i < F) v = __fmul_rn(v, 0.5f * (1.0f - cosf(linspace_f32(0.f, 3.14159265358979323846f, F, (int)i))));
+        if (fades && (flags & RT_STREAM_FADE_OUT) && i >= m - F) v = __fmul_rn(v, 0.5f * (1.0f + cosf(linspace_f32(0.f, 3.14159265358979323846f, F, (int)(i - (m - F))))));
+        out[i] = v;
+    }
+    if (threadIdx.x == 0) { st->dc = dc_d; st->gain = gain_d; st->out_len = m; st->start = lo; }
+}
+
 int post_impl(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32_t* first, const float* const* seg_ptr,
               const int64_t* seg_len, const uint8_t* seg_trim, float* const* out_ptr, const int64_t* out_cap,
               rt_post_stats* h_stats, bool host_buffers) {
@@ -521,6 +594,29 @@ int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_pcm16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_in, n, d_out);
     RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_stream_chunk(rt_ctx* ctx, const rt_post_params* p, const float* d_in, int64_t n, uint32_t flags, double* h_dc_gain, float* d_out,
+                    int64_t* h_out_len) {
+    if (!ctx || !p || !h_dc_gain || !h_out_len || n < 0 || (n > 0 && (!d_in || !d_out))) return rt_fail(ctx, RT_ERR_INVALID, "rt_stream_chunk: null argument");
+    if (p->window < 2 || p->fade < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_stream_chunk: bad geometry (window=%d fade=%d)", p->window, p->fade);
+    *h_out_len = 0;
+    if (n == 0) return RT_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    void *dv = nullptr, *hv = nullptr;
+    RT_TRY_POST(rt_ctx_scratch(ctx, sizeof(StreamState), &dv));
+    RT_TRY_POST(rt_ctx_pinned(ctx, sizeof(StreamState), &hv));
+    StreamState* hs = (StreamState*)hv;
+    hs->dc = h_dc_gain[0]; hs->gain = h_dc_gain[1]; hs->out_len = 0; hs->start = 0;
+    RT_HIP(ctx, hipMemcpyAsync(dv, hs, sizeof(StreamState), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_stream_chunk, dim3(1), dim3(kThreads), 0, ctx->stream, *p, d_in, n, flags, (StreamState*)dv, d_out);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(hs, dv, sizeof(StreamState), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h_dc_gain[0] = hs->dc; h_dc_gain[1] = hs->gain;
+    *h_out_len = hs->out_len;
     return RT_OK;
 }
 

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
             const float inv = rsqrtf(ss / (float)d + eps);
             if (act) { a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv); }
         }
-        if (act) {
+        if (act && cosT) {                           // (cosT == nullptr: no rotary embedding - learned / sinusoidal positions, stt.hip)
             const float c = cosT[(int64_t)pos * half + lane], s = sinT[(int64_t)pos * half + lane];
             const float ra = a * c - b * s, rb = b * c + a * s;
             a = ra; b = rb;

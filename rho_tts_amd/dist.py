@@ -155,6 +155,52 @@ def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=No
     return None
 
 
+def gather_rows(rows: torch.Tensor, dist, dst: int = 0, device=None) -> Optional[List[torch.Tensor]]:
+    """Per-item records beside the waveforms (segment counts, decay ratios, validation scores): ``rows`` is [n_local, k]
+    float64; returns on ``dst`` one [n_r, k] CPU tensor per rank, else None.  One count exchange + one padded gather."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or rows.device
+    k = int(rows.shape[1])
+    n_local = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    cap = max(1, max(int(c) for c in counts))
+    pad = torch.zeros(cap, k, dtype=torch.float64, device=device)
+    pad[: rows.shape[0]] = rows.to(device=device, dtype=torch.float64)
+    if rank == dst:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, gather_list=bufs, dst=dst)
+        return [bufs[r][: int(counts[r])].cpu() for r in range(world)]
+    dist.gather(pad, gather_list=None, dst=dst)
+    return None
+
+
+def agree(dist, device, code: int) -> int:
+    """Largest status code over the ranks (one tiny all-reduce): every rank learns whether any rank failed BEFORE the next
+    collective, so that a failure on one rank ends the call on all of them instead of leaving the others waiting."""
+    t = torch.tensor([int(code)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
+    """One process per GPU under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment): initialise the process group - "nccl" IS RCCL on ROCm - BEFORE anything touches the GPU, and return
+    (rank, local_rank, world).  Build the provider with ``device=f"cuda:{local_rank}"`` afterwards."""
+    import os
+
+    import torch.distributed as td
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if not td.is_initialized():
+        if backend == "nccl":
+            td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            td.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
 def unshard(per_rank: Sequence[Sequence], shards: Sequence[Sequence[int]], n_total: int) -> List:
     """Inverse of ``shard_items``: place rank r's k-th result at original index shards[r][k]."""
     out = [None] * n_total

@@ -94,6 +94,11 @@ class Engine:
         self.tokenizer = load_tokenizer(model_path, self.cfg.text_vocab)
         self.voice: Optional[VoiceConditioning] = None
         self.params = GenerationParams()
+        # Synthetic weights never emit end-of-sequence, so every length is imposed (frames_for).  A real checkpoint ends where
+        # its end-of-sequence falls, somewhere around the planner's estimate: length_jitter = e emulates that - every text ends
+        # at estimate x (1 + e (2u - 1)), u a hash of the text (the same alone and in any batch) - while schedules are still
+        # planned on the estimates.  Benchmarks and scheduling tests only; 0 = lengths as estimated.
+        self.length_jitter = 0.0
 
     def close(self) -> None:
         if getattr(self, "model", None) is not None:
@@ -134,13 +139,21 @@ class Engine:
             return max(2, min(cap, int(round(rate * FRAME_SECONDS_PER_WORD * n_words))))
         return max(2, min(cap, 8 + 6 * n_tokens))            # eos-terminated; generous cap of ~0.5 s per token
 
+    def frames_actual(self, text: str, n_tokens: int) -> int:
+        f = self.frames_for(text, n_tokens)
+        if self.synthetic and self.length_jitter > 0:
+            import zlib
+            u = (zlib.crc32(text.encode()) & 0xFFFFFF) / float(1 << 24)
+            f = max(2, int(round(f * (1.0 + self.length_jitter * (2.0 * u - 1.0)))))
+        return f
+
     # ------------------------------------------------------------------ generate
     def generate_codes(self, texts: Sequence[str], seed: int, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
                        max_frames: Optional[Sequence[int]] = None, max_rows: int = 0) -> List[torch.Tensor]:
         if self.voice is None:
             raise ValueError("no voice set: reference audio (Base models) or a built-in speaker (CustomVoice) is required")
         ids = [self.tokenizer.encode(t) for t in texts]
-        frames = list(max_frames) if max_frames is not None else [self.frames_for(t, len(i)) for t, i in zip(texts, ids)]
+        frames = list(max_frames) if max_frames is not None else [self.frames_actual(t, len(i)) for t, i in zip(texts, ids)]
         limit = self.model.max_positions - self.model.prefix_len() - 12     # (queued items step a few positions past their last frame)
         for i, f in zip(ids, frames):
             if len(i) + 2 + f > limit:
@@ -171,6 +184,54 @@ class Engine:
                     start = end
                 out[i] = torch.cat(parts)
         return out  # type: ignore[return-value]
+
+    # ------------------------------------------------------------------ sub-segment streaming
+    def stream_codes(self, text: str, seed: int = 789, item_id: int = 0, first_chunk: int = 12, chunk: int = 36, cancel_flag=None,
+                     max_frames: Optional[int] = None):
+        """One text decoded in pieces (rt_generate_begin / _step / _peek / _end): yields ``(codes [n, n_groups] int64, last)`` as
+        the frames come off the GPU - ``first_chunk`` frames first (time to first audio), then ``chunk`` at a time.  The codes
+        are those of the one-call ``generate_codes`` for the same (text, seed, item_id), however they are cut."""
+        if self.voice is None:
+            raise ValueError("no voice set: reference audio (Base models) or a built-in speaker (CustomVoice) is required")
+        ids = self.tokenizer.encode(text)
+        frames = int(max_frames) if max_frames is not None else self.frames_actual(text, len(ids))
+        limit = self.model.max_positions - self.model.prefix_len() - 12
+        if len(ids) + 2 + frames > limit:
+            raise RuntimeError(f"length: text of {len(ids)} tokens + {frames} frames exceeds the {limit} free KV rows")
+        ignore_eos = self.synthetic if self.ignore_eos is None else bool(self.ignore_eos)
+        self.model.generate_begin([ids], [frames], self.params.talker(), self.params.predictor(), seed=seed, item_ids=[item_id],
+                                  ignore_eos=ignore_eos, cancel_flag=cancel_flag)
+        try:
+            sent, step = 0, max(1, int(first_chunk))
+            while True:
+                _, done = self.model.generate_step(step)
+                codes, _ = self.model.generate_peek(0, sent, frames)
+                sent += int(codes.shape[0])
+                if codes.shape[0] or done:
+                    yield codes, done
+                if done:
+                    return
+                step = max(1, int(chunk))
+        finally:
+            self.model.generate_end()
+
+    def stream_wav(self, text: str, seed: int = 789, item_id: int = 0, first_chunk: int = 12, chunk: int = 36, cancel_flag=None,
+                   max_frames: Optional[int] = None):
+        """Raw waveform chunks (GPU float32) of one text while it is still being decoded: every batch of new codec frames is
+        vocoded with ``left_context_frames`` of the frames before it and the context's samples are dropped - the codec decoder's
+        own chunked decode (chunk boundaries where the frames arrive instead of every ``chunk_frames``).  Yields ``(wav, last)``."""
+        c = self.cfg.codec
+        have: Optional[torch.Tensor] = None
+        for codes, last in self.stream_codes(text, seed, item_id, first_chunk, chunk, cancel_flag, max_frames):
+            if codes.shape[0] == 0:
+                if last:
+                    yield torch.zeros(0, device=self.device), True
+                continue
+            start = 0 if have is None else int(have.shape[0])
+            have = codes if have is None else torch.cat([have, codes])
+            ctx = c.left_context_frames if start - c.left_context_frames > 0 else start
+            w = self.model.code2wav([have[start - ctx:]])[0]
+            yield w[ctx * c.total_upsample:], last
 
     def plan_batches(self, frames: Sequence[int]) -> List[List[int]]:
         """Batches of ``max_batch`` text indices.  One batch keeps arrival order; more are bucketed by frame budget, longest
@@ -209,8 +270,13 @@ class Engine:
         if max_frames is not None:
             frames = [int(f) for f in max_frames]
         else:
-            frames = [self.frames_for(t, len(self.tokenizer.encode(t))) for t in texts]
-        plan = [int(f) for f in plan_frames] if plan_frames is not None else frames
+            frames = [self.frames_actual(t, len(self.tokenizer.encode(t))) for t in texts]
+        if plan_frames is not None:
+            plan = [int(f) for f in plan_frames]
+        elif max_frames is None and self.synthetic and self.length_jitter > 0:
+            plan = [self.frames_for(t, len(self.tokenizer.encode(t))) for t in texts]      # the estimates, not the jittered lengths
+        else:
+            plan = frames
         wavs: List[Optional[torch.Tensor]] = [None] * n
         rows = self.pick_rows(plan)
         if continuous is None:

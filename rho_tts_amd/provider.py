@@ -50,19 +50,33 @@ class BatchedPipeline:
     """
 
     def _run_pipeline(self, texts, cancellation_token, progress_callback=None):
-        token = cancellation_token
+        plans = self._plan_texts(texts, cancellation_token)
+        return self._run_plans(plans, list(range(len(plans))), cancellation_token, progress_callback)
+
+    def _plan_texts(self, texts, token) -> List[List[str]]:
+        """Phonetic mapping, then segmentation per text with the memory-aware limit (base_tts.py:721,727-731)."""
         mapped = [self._apply_phonetic_mapping(t) for t in texts]
         plans: List[List[str]] = []
         for idx, text in enumerate(mapped):
             if token.is_cancelled():
                 raise CancelledException(f"Cancelled during text item {idx}")
             plans.append(self._split_text_into_segments(text, self._compute_max_chars()))
-        n = len(mapped)
+        return plans
+
+    def _run_plans(self, plans, owned, token, progress_callback=None):
+        """The pipeline for the text items ``owned`` (indices into ``plans``; all of them on one GPU, this rank's share in a
+        data-parallel run).  Returns one entry per owned item, in that order.  The RNG stream of a segment is its position in
+        the work list of ALL items, owned or not: a text's audio does not depend on how many ranks shared the list."""
+        seg_base, tot = [], 0
+        for pl in plans:
+            seg_base.append(tot)
+            tot += len(pl)
+        n = len(plans)
         final: List[Optional[torch.Tensor]] = [None] * n
         seg_audio: List[List[torch.Tensor]] = [[] for _ in range(n)]
         decay: List[Tuple[float, bool]] = [(0.0, True)] * n
         scores: List[Tuple[List[float], List[float]]] = [([], []) for _ in range(n)]
-        pending = list(range(n))
+        pending = list(owned)
         for attempt in range(self.max_decay_retries):
             if not pending:
                 break
@@ -72,7 +86,7 @@ class BatchedPipeline:
             work = [(i, s, seg) for i in pending for s, seg in enumerate(plans[i])]
             for i in pending:
                 seg_audio[i], scores[i] = [], ([], [])
-            got = self._generate_work(work, plans, token, progress_callback, scores)
+            got = self._generate_work(work, plans, token, progress_callback, scores, [seg_base[i] + s for i, s, _ in work])
             for (i, s, _), a in zip(work, got):
                 if a is not None:
                     seg_audio[i].append(a)
@@ -89,7 +103,7 @@ class BatchedPipeline:
                     still.append(i)
             pending = still
         out: List[Optional[Tuple[torch.Tensor, int, dict]]] = []
-        for i in range(n):
+        for i in owned:
             if final[i] is None or not seg_audio[i]:
                 logger.error(f"Item {i + 1} failed: no audio generated")
                 out.append(None)
@@ -104,7 +118,9 @@ class BatchedPipeline:
         return out
 
     # one entry of `work` per (item, segment index, text); returns the accepted audio (or None) per entry
-    def _generate_work(self, work, plans, token, progress_callback, scores):
+    def _generate_work(self, work, plans, token, progress_callback, scores, stream_ids=None):
+        if stream_ids is None:
+            stream_ids = list(range(len(work)))
         accepted: List[Optional[torch.Tensor]] = [None] * len(work)
         # per-segment validation state, exactly the reference's locals (base_tts.py:765-768): best audio by drift, the
         # MINIMUM drift seen, the LAST text similarity computed (whenever the voice check passed), the last audio
@@ -125,8 +141,9 @@ class BatchedPipeline:
                     if progress_callback and iteration == 0:
                         progress_callback(f"Generating segment {s + 1}/{len(plans[i])}...")
                 self._set_seeds()
-                # RNG stream of a segment = its index in the work list: independent of how the list is cut into batches
-                audios = self._generate_chunk([work[w][2] for w in chunk], list(chunk), token)
+                # RNG stream of a segment = its index in the work list of the whole call: independent of how the list is cut into
+                # batches and of how many ranks share it
+                audios = self._generate_chunk([work[w][2] for w in chunk], [stream_ids[w] for w in chunk], token)
                 for w, a in zip(chunk, audios):
                     if a is None:
                         retry.append(w)
@@ -280,6 +297,122 @@ class BatchedPipeline:
         return cm()
 
 
+class DataParallelPipeline(BatchedPipeline):
+    """``_run_pipeline`` across the GPUs of a node (BASELINE.json configs[3]): one process per GPU under
+    ``torch.distributed`` (backend "nccl" = RCCL over xGMI), every rank calling ``generate()`` with the SAME texts.
+    The reference's loop over texts is strictly sequential (base_tts.py:726-954) and keeps no state between items, so whole text
+    items are the unit: they are dealt over the ranks by estimated decode length (dist.shard_items), every rank runs its share
+    through the batched pipeline above (continuous batching on its decode rows, validation and decay retries included), and the
+    finished waveforms + per-item records are gathered to rank 0 and put back in the caller's order.  Two collectives carry
+    data - the broadcast of the voice conditioning rank 0 computed (once per voice) and the gather of the waveforms - plus
+    one-word status exchanges so that a failure on one rank ends the call on all of them.
+    Rank 0 returns the complete result list; the other ranks return their own items and ``None`` elsewhere (``generate()`` on
+    them returns nothing and saves nothing: MI355XQwenTTS.generate).  A text's audio is a function of (text, voice, seed,
+    position in the call), not of the number of ranks.
+    ``data_parallel``: "auto" (on when a process group with more than one rank is initialised), True, False."""
+
+    data_parallel = "auto"
+
+    def _dp(self):
+        mode = getattr(self, "data_parallel", "auto")
+        if mode is False or mode in ("off", "0"):
+            return None
+        import os
+
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized()):
+            if mode is True:
+                raise ValueError("data_parallel=True needs an initialised torch.distributed process group "
+                                 "(launch one process per GPU with torch.distributed.run; rho_tts_amd.dist.init_from_env)")
+            return None
+        world = td.get_world_size()
+        forced = mode is True or os.environ.get("RHO_TTS_AMD_FORCE_DIST", "") not in ("", "0")    # (one rank: exercises the RCCL call sites)
+        if world < 2 and not forced:
+            return None
+        return td, td.get_rank(), world
+
+    def _dp_device(self, td) -> torch.device:
+        return torch.device(self.device) if str(td.get_backend()) == "nccl" else torch.device("cpu")
+
+    @staticmethod
+    def _dp_agree(td, dev, err: Optional[BaseException], what: str) -> None:
+        from . import dist as D
+        code = 0 if err is None else (2 if isinstance(err, CancelledException) else (3 if isinstance(err, ValueError) else 1))
+        worst = D.agree(td, dev, code)
+        if err is not None:
+            raise err
+        if worst == 2:
+            raise CancelledException(f"cancelled on another rank during {what}")
+        if worst == 3:
+            raise ValueError(f"configuration error on another rank during {what}")
+        if worst:
+            raise RuntimeError(f"another rank failed during {what}")
+
+    def _dp_share_voice(self, td, rank: int, dev) -> None:
+        """Rank 0 computes the conditioning (audio encoder + prefix prefill), everyone else imports its KV blob."""
+        raise NotImplementedError
+
+    def _dp_costs(self, plans) -> List[float]:
+        out = []
+        for pl in plans:
+            c = 0.0
+            for seg in pl:
+                e = self._estimate_cost(seg)
+                c += float(e) if e is not None else float(max(1, len(seg.split())))
+            out.append(c)
+        return out
+
+    def _run_pipeline(self, texts, cancellation_token, progress_callback=None):
+        dp = self._dp()
+        if dp is None:
+            return super()._run_pipeline(texts, cancellation_token, progress_callback)
+        from . import dist as D
+        td, rank, world = dp
+        dev = self._dp_device(td)
+        plans, err = [], None
+        try:
+            plans = self._plan_texts(texts, cancellation_token)        # the same on every rank
+        except BaseException as e:  # noqa: BLE001  (a token cancelled on ONE rank: re-raised by _dp_agree, on every rank)
+            err = e
+        self._dp_agree(td, dev, err, "planning")
+        self._dp_share_voice(td, rank, dev)
+        shards = D.shard_items(self._dp_costs(plans), world)
+        local = []
+        try:
+            local = self._run_plans(plans, shards[rank], cancellation_token, progress_callback)
+        except BaseException as e:  # noqa: BLE001  (re-raised by _dp_agree, on every rank)
+            err = e
+        self._dp_agree(td, dev, err, "generation")
+        nan = float("nan")
+        wavs = [None if r is None else r[0].reshape(-1) for r in local]
+        rows = torch.tensor([[0.0, nan, nan, nan, 0.0] if r is None else
+                             [float(r[1]), float(r[2]["decay_ratio"]), float(r[2].get("drift_prob", nan)), float(r[2].get("text_similarity", nan)),
+                              1.0 if r[0].dim() == 2 else 0.0] for r in local], dtype=torch.float64).reshape(len(local), 5)
+        per_rank = D.gather_waveforms(wavs, td, dst=0, device=dev)
+        recs = D.gather_rows(rows, td, dst=0, device=dev)
+        if rank != 0:
+            out: List[Optional[Tuple[torch.Tensor, int, dict]]] = [None] * len(plans)
+            for i, r in zip(shards[rank], local):
+                out[i] = r
+            return out
+        items = []
+        for r in range(world):
+            got = []
+            for w, rec in zip(per_rank[r], recs[r].tolist()):
+                if w is None:
+                    got.append(None)
+                    continue
+                meta = {}
+                if rec[2] == rec[2]:
+                    meta["drift_prob"] = rec[2]
+                if rec[3] == rec[3]:
+                    meta["text_similarity"] = rec[3]
+                meta["decay_ratio"] = rec[1]
+                got.append((w.unsqueeze(0) if rec[4] else w, int(rec[0]), meta))
+            items.append(got)
+        return D.unshard(items, shards, len(plans))
+
+
 class HipAudioLeaves:
     """The numeric leaves of the pipeline as calls into the fused HIP kernel (one stage mask each).
     Reference: base_tts.py:297-536, providers/qwen.py:268-378.  Inputs may be CPU or GPU tensors; the result lives
@@ -354,7 +487,7 @@ class HipAudioLeaves:
         return [(o.unsqueeze(0) if s.all_silent else o, s.decay_ratio, bool(s.decay_ok)) for o, s in zip(outs, stats)]
 
 
-class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
+class MI355XQwenTTS(DataParallelPipeline, HipAudioLeaves, BaseTTS):
     """Qwen3-TTS generation on one MI355X.  Same keyword arguments as the reference's ``QwenTTS``."""
 
     MAX_MODEL_CHARS = 4000
@@ -391,6 +524,9 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
         self._ctx = None
         self._lock = threading.RLock()
         self._voice_key = None
+        # decode-schedule figures of this instance's engine calls, accumulated until cleared: kept / launched row-frames
+        # ("frames" / "padded_frames": their quotient is the row occupancy), rt_generate calls, row hand-overs
+        self.last_schedule: Dict[str, int] = {}
 
     # ---------------------------------------------------------------- native handles
     def _device_ordinal(self) -> int:
@@ -419,7 +555,8 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
                 self._max_model_chars = min(self.MAX_MODEL_CHARS, hf_pos) if hf_pos > 0 else self.MAX_MODEL_CHARS
             return self._engine
 
-    def _ensure_voice(self, eng) -> None:
+    def _voice_config_key(self):
+        """The mode checks of QwenTTS._generate_audio (qwen.py:231-242), and what identifies the configured voice."""
         is_custom = "CustomVoice" in self.model_path
         if is_custom and not self.speaker:
             raise ValueError("CustomVoice model requires a named speaker. Select a built-in voice (e.g. Vivian, Ryan) "
@@ -427,7 +564,30 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
         if not is_custom and not self.voice_cloning:
             raise ValueError("Qwen Base model requires reference audio for voice cloning. "
                              "Use a CustomVoice model with a named speaker, or provide reference audio.")
-        key = (self.speaker, self.language) if is_custom else (self.reference_audio_path, self.reference_text, self.language)
+        return (self.speaker, self.language) if is_custom else (self.reference_audio_path, self.reference_text, self.language)
+
+    def _dp_share_voice(self, td, rank: int, dev) -> None:
+        from . import dist as D
+        eng, err, key = None, None, None
+        try:
+            eng = self._load_engine()
+            key = self._voice_config_key()
+            if key != self._voice_key and rank == 0:
+                with self._lock:
+                    self._ensure_voice(eng)
+        except BaseException as e:  # noqa: BLE001  (re-raised below, on every rank)
+            err = e
+        self._dp_agree(td, dev, err, "voice conditioning")
+        # (`_dp_voice_sent` only changes here, on every rank at once - every rank runs the same calls with the same configuration -
+        # so the ranks agree on whether the broadcast is due)
+        if getattr(self, "_dp_voice_sent", None) != key:
+            D.broadcast_voice(eng, td, src=0, comm_device=dev)
+            self._voice_key = key
+            self._dp_voice_sent = key
+
+    def _ensure_voice(self, eng) -> None:
+        is_custom = "CustomVoice" in self.model_path
+        key = self._voice_config_key()
         if key == self._voice_key:
             return
         if is_custom:
@@ -487,7 +647,7 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
         try:
             with self._lock:
                 self._ensure_voice(eng)
-                wavs = eng.synthesize(texts, seed=int(self.seed), item_ids=kwargs.get("item_ids"), cancel_flag=flag)
+                wavs = eng.synthesize(texts, seed=int(self.seed), item_ids=kwargs.get("item_ids"), cancel_flag=flag, stats=self.last_schedule)
         except _native.CancelledError as e:
             raise CancelledException(str(e))
         finally:
@@ -495,6 +655,28 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
             if watcher is not None:
                 watcher.join(timeout=1.0)
         return wavs[0] if single else wavs
+
+    def generate(self, texts, output_path: Optional[str] = None, cancellation_token: Optional[CancellationToken] = None,
+                 format: str = "wav", speed: float = 1.0, pitch_semitones: float = 0.0, progress_callback: Optional[Callable[[str], None]] = None):
+        """``BaseTTS.generate`` (base_tts.py:960-1101), inherited unchanged - except on the WORKER ranks of a data-parallel run
+        (DataParallelPipeline): those do their share of the texts, deliver it to rank 0 and return nothing (``None`` for one
+        text, a list of ``None`` for a list) without writing any file; rank 0 returns and saves everything."""
+        dp = self._dp()
+        if dp is None or dp[1] == 0:
+            return super().generate(texts, output_path, cancellation_token, format, speed, pitch_semitones, progress_callback)
+        if format not in ("wav", "mp3", "flac", "ogg"):          # the check rank 0 makes before it enters the pipeline (base_tts.py:996-999)
+            from .api import FormatConversionError
+            raise FormatConversionError(f"Unsupported format '{format}'. Supported: flac, mp3, ogg, wav")
+        single = isinstance(texts, str)
+        try:
+            self._run_pipeline([texts] if single else list(texts), cancellation_token or CancellationToken(), progress_callback)
+        except CancelledException as e:
+            logger.warning(f"Generation cancelled: {e}")
+        except ValueError:
+            raise
+        except Exception as e:  # noqa: BLE001  (as the inherited generate does: log, return nothing)
+            logger.error(f"Error in TTS generation: {e}")
+        return None if single else [None] * len(texts)
 
     def stream(self, text: str, cancellation_token: Optional[CancellationToken] = None, speed: float = 1.0,
                pitch_semitones: float = 0.0):
@@ -506,6 +688,9 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
         from .api import GenerationResult
         token = cancellation_token or CancellationToken()
         segments = self._split_text_into_segments(self._apply_phonetic_mapping(text), self._compute_max_chars())
+        if int(getattr(self, "stream_chunk_frames", 0) or 0) > 0:
+            yield from self._stream_chunks(segments, token, speed, pitch_semitones)
+            return
 
         def finish(raw: torch.Tensor):
             audio = self._post_process_audio(raw)
@@ -543,6 +728,47 @@ class MI355XQwenTTS(BatchedPipeline, HipAudioLeaves, BaseTTS):
                     yield finish(raw)
                 except Exception as e:  # noqa: BLE001
                     logger.warning(f"Segment {first + k + 1} failed: {e}")
+
+    # Opt-in SUB-SEGMENT streaming (an extension: the reference hands audio over per segment): with ``stream_chunk_frames`` = n > 0,
+    # ``stream()`` yields the first n codec frames of a segment (n x 80 ms of audio) as soon as they are decoded and vocoded, then
+    # the rest in pieces of ``stream_next_chunk_frames`` while the decode goes on - one GenerationResult per piece, to be played
+    # back to back.  Loudness gain and DC offset are taken from a segment's first piece and kept (rt_stream_chunk); trims and
+    # fades happen at the segment's two ends only.
+    stream_chunk_frames = 0
+    stream_next_chunk_frames = 36
+
+    def _stream_chunks(self, segments, token, speed, pitch_semitones):
+        from .api import GenerationResult
+        eng = self._load_engine()
+        params = self._post_params(0)
+        for seg_idx, seg in enumerate(segments):
+            if token.is_cancelled():
+                return
+            self._set_seeds()
+            flag = C.c_int32(0)
+            state = [0.0, 1.0]
+            try:
+                with self._lock:
+                    self._ensure_voice(eng)
+                    k = 0
+                    for raw, last in eng.stream_wav(seg, seed=int(self.seed), item_id=0, first_chunk=int(self.stream_chunk_frames),
+                                                    chunk=int(self.stream_next_chunk_frames), cancel_flag=flag):
+                        if token.is_cancelled():
+                            flag.value = 1
+                            return
+                        audio = self._native_ctx().stream_chunk(params, raw, state, first=(k == 0), last=last) if raw.numel() else raw
+                        k += 1
+                        if audio.numel() == 0:
+                            continue
+                        if speed != 1.0 or pitch_semitones != 0.0:
+                            audio = self._apply_speed_pitch(audio, speed, pitch_semitones)
+                        n_samples = audio.shape[-1] if audio.dim() == 2 else audio.numel()
+                        yield GenerationResult(audio=audio, sample_rate=self.sample_rate, duration_sec=n_samples / self.sample_rate,
+                                               segments_count=1, format="wav")
+            except _native.CancelledError:
+                return
+            except Exception as e:  # noqa: BLE001  (as the reference: a failed segment is skipped, base_tts.py:1166-1168)
+                logger.warning(f"Segment {seg_idx + 1} failed: {e}")
 
     @property
     def sample_rate(self) -> int:

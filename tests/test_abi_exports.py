@@ -29,7 +29,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_status_strings():
     lib = _native.load_library()
-    assert lib.rt_abi_version() == 4
+    assert lib.rt_abi_version() == 5
     assert lib.rt_status_string(0) == b"ok"
     assert b"memory" in lib.rt_status_string(_native.RT_ERR_OOM)
 

@@ -26,7 +26,13 @@ TTSFactory._default_providers_registered = True              # never let default
 from rho_tts_amd.provider import MI355XQwenTTS, PROVIDER_NAME, register
 assert register() == PROVIDER_NAME and TTSFactory._providers[PROVIDER_NAME] is MI355XQwenTTS
 assert issubclass(MI355XQwenTTS, B.BaseTTS)
-assert MI355XQwenTTS.generate is B.BaseTTS.generate                                                    # inherited, not re-implemented
+# generate() is the reference's own: the provider's thin override only steps in on the worker ranks of a data-parallel run
+_o = MI355XQwenTTS.__new__(MI355XQwenTTS); _o.data_parallel = False
+_seen = []
+_orig = B.BaseTTS.generate
+B.BaseTTS.generate = lambda self, *a, **k: _seen.append((a, k)) or "inherited"
+assert MI355XQwenTTS.generate(_o, ["x"], None, None, "wav") == "inherited" and _seen and _seen[0][0][0] == ["x"]
+B.BaseTTS.generate = _orig
 assert MI355XQwenTTS.stream is not B.BaseTTS.stream        # same results per segment, two batched calls (tests/test_provider_gpu.py)
 assert MI355XQwenTTS._run_pipeline is not B.BaseTTS._run_pipeline                                     # the batching seam
 assert api.CancelledException is rho_tts.CancelledException and api.GenerationResult is rho_tts.GenerationResult

@@ -109,3 +109,33 @@ def test_known_answers_survey_8c(golden_post):
 def test_pcm16_truncates():
     x = np.array([0.0, 0.5, -0.5, 1.5, -1.5, 0.99999], np.float32)
     assert O.pcm16(x).tolist() == [0, 16383, -16383, 32767, -32767, 32766]
+
+
+def test_stream_chunk_of_a_whole_segment_is_the_references_stream_tail():
+    """oracle.stream_chunk (the oracle of rt_stream_chunk, sub-segment streaming): a segment handed over as ONE chunk (first and
+    last at once) is exactly the per-segment tail of the reference's stream() - _post_process_audio -> _trim_silence ->
+    _remove_dc_offset -> _apply_fades (base_tts.py:1170-1176), here through the pinned leaves - and cutting it into chunks only
+    changes where the DC offset and the gain were measured."""
+    import numpy as np
+    import torch
+    from oracle import postprocess as OP
+    p = OP.PostParams(sample_rate=24000)
+    g = np.random.default_rng(3)
+    n = 60000
+    t = np.arange(n) / 24000.0
+    x = (0.2 * np.sin(2 * np.pi * 190.0 * t) + 0.01 * g.standard_normal(n) + 0.003).astype(np.float32)
+    x[:3000] = 0
+    x[-2500:] = 0
+    want = OP.apply_fades(OP.remove_dc(OP.trim_silence(OP.loudness_post_process(x, p), p)), p)
+    st = [0.0, 1.0]
+    got = OP.stream_chunk(x, p, st, True, True)
+    assert got.shape == want.shape and float((got - want).abs().max()) < 1e-6
+    st2 = [0.0, 1.0]
+    parts = [OP.stream_chunk(x[a:b], p, st2, a == 0, b == n) for a, b in ((0, 20000), (20000, 41000), (41000, n))]
+    cat = torch.cat(parts)
+    # the leading trim is the same; the trailing one is taken on the last chunk's own 5-ms frame grid: within one window
+    assert abs(cat.shape[0] - want.shape[0]) <= p.window
+    assert abs(st2[1] / st[1] - 1.0) < 0.25
+    mid = slice(25000, 30000)                                            # away from the fades: the same waveform up to gain and dc
+    k = float((cat[mid] * want[mid]).sum() / (want[mid] ** 2).sum())
+    assert float((cat[mid] - k * want[mid]).abs().max()) < 5e-3
