@@ -46,6 +46,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PMC_PROFILE = "r03_pmc_fetch_bench_step.json"      # counter pass over this bench's own step (tools/pmc_step_split.py), keyed on the library's hash
+
 WORDS = ("time year people way day man thing woman life child world school state family student group country problem hand "
          "part place case week company system program question work government number night point home water room mother area "
          "money story fact month lot right study book eye job word business issue side kind head house service friend father "
@@ -223,19 +225,34 @@ def main():
             # HBM-side bytes per launch: counters cannot be read from inside this process, so `traffic` is the FETCH_SIZE of the
             # SAME step (same model, batch, prompt and launch sequence) collected by `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py
             # --steps 1 --warmup 0 --tune 200,1301` and reduced by tools/pmc_step_split.py (x 1024 x 2: KiB, gfx950 correction)
+            # The counters belong to ONE build of the library: the profile records the SHA-256 of librho_tts_amd.so it was taken with, and
+            # a different library (any kernel change) reports traffic = null rather than stale bytes.
             default_workload = args.model == "1.7b" and B == 32 and args.words == 10 and args.ref_seconds == 30.0 and corpus is None
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_bench_step.json")) as f:
+                import hashlib
+                with open(os.path.join(ROOT, "rho_tts_amd", "librho_tts_amd.so"), "rb") as f:
+                    lib_sha = hashlib.sha256(f.read()).hexdigest()
+                with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
                     pmc = json.load(f)
-                if default_workload and pmc["k_gemm_col_dispatches"] == int(n_l):
+                roof["lib_sha256"] = lib_sha[:16]
+                if default_workload and pmc["k_gemm_col_dispatches"] == int(n_l) and pmc.get("lib_sha256", "")[:16] == lib_sha[:16]:
                     roof["traffic"] = float(pmc["all"]["fetched_bytes_per_dispatch"])
                     roof["traffic_source"] = ("FETCH_SIZE x 1024 x 2 per k_gemm_col dispatch, counter pass over bench.py itself "
-                                              "(profiles/r02_pmc_fetch_bench_step.json: fetched / algorithmic = %.3f; talker layers %.3f, "
+                                              "(profiles/" + PMC_PROFILE + ": fetched / algorithmic = %.3f; talker layers %.3f, "
                                               "predictor layers %.3f - the predictor is Infinity-Cache resident, FETCH_SIZE counts its L2 misses)"
                                               % (pmc["all"]["fetched_over_algorithmic"], pmc["classes"]["talker layers"]["fetched_over_algorithmic"],
                                                  pmc["classes"]["predictor layers"]["fetched_over_algorithmic"]))
+                elif default_workload:
+                    roof["traffic_source"] = ("null: profiles/" + PMC_PROFILE + " was collected with another build of librho_tts_amd.so "
+                                              "(sha256 %s..., %d k_gemm_col dispatches) - re-run tools/pmc_step_split.py" % (pmc.get("lib_sha256", "?")[:16], pmc["k_gemm_col_dispatches"]))
+                # HBM GB/s and MFMA-busy per kernel family against the chip's peaks (north_star): from the committed rocprofv3 passes of
+                # this same build (kernel trace for time, FETCH_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes for bytes and matrix-core use)
+                if pmc.get("lib_sha256", "")[:16] == lib_sha[:16] and "families" in pmc:
+                    extra_families = pmc["families"]
+                else:
+                    extra_families = None
             except (OSError, KeyError, ValueError):
-                pass
+                extra_families = None
         # decode-step view: algorithmic bytes per frame for the local batch
         t_, p_ = cfg.talker, cfg.predictor
         w_talker = 2 * (t_.weight_params() + t_.hidden * cfg.codec_vocab)
@@ -245,6 +262,8 @@ def main():
         ctx_len = eng.model.prefix_len() + args.words + 3 + frames // 2
         kv = B * ctx_len * t_.layers * 2 * t_.kv_heads * t_.head_dim * 2
         extra = {"bytes_per_frame": int(w_talker + w_pred + kv), "frames_per_item": frames, "prefix_rows": eng.model.prefix_len()}
+        if roof is not None and locals().get("extra_families"):
+            extra["kernel_families"] = extra_families
     if corpus is not None:
         extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(actual)), "length_error": args.length_error,
                       # rows kept busy by the decode schedule of rank 0, measured (kept frames / (frames launched x rows));
@@ -269,6 +288,22 @@ def main():
             tt.append((time.perf_counter() - t1) * 1e3)
         extra["ttfa_ms_one_text"] = round(min(tt), 2)
         extra["ttfa_audio_s"] = round(o1[0].numel() / cfg.sample_rate, 2)
+        # ... and of the SUB-SEGMENT streaming entry (provider.stream with stream_chunk_frames = 12, an extension): call -> the first
+        # 12 codec frames decoded (rt_generate_begin / _step), vocoded, levelled / trimmed / faded (rt_stream_chunk), 16-bit PCM on the host
+        tc, first_s = [], 0.0
+        for _ in range(3):
+            sync()
+            t1 = time.perf_counter()
+            state = [0.0, 1.0]
+            gen = eng.stream_wav(one[0], seed=789, item_id=0, first_chunk=12, chunk=36)
+            raw, last = next(gen)
+            piece = eng.ctx.stream_chunk(post, raw, state, True, last)
+            _pcm = eng.ctx.pcm16(piece).cpu()
+            tc.append((time.perf_counter() - t1) * 1e3)
+            first_s = piece.numel() / cfg.sample_rate
+            gen.close()
+        extra["ttfa_ms_first_chunk"] = round(min(tc), 2)
+        extra["ttfa_first_chunk_audio_s"] = round(first_s, 2)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -320,7 +355,8 @@ def cpu_baseline(cfg, args, eng):
     from rho_tts_amd.voice import synthetic_reference_clip
     from rho_tts_amd.weights import synthetic_state
 
-    cores = min(os.cpu_count() or 1, 32)          # eager PyTorch stops scaling (and small ops get slower) past ~32 threads
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 32)                   # eager PyTorch stops scaling (and small ops get slower) past ~32 threads
     torch.set_num_threads(cores)
     log(f"cpu baseline: copying weights to the host ({cores} cores) ...")
     state = {k: v.cpu() for k, v in synthetic_state(cfg, 789, device=eng.device).items()}
@@ -356,7 +392,7 @@ def cpu_baseline(cfg, args, eng):
     scale = full_frames / frames
     t_full = cond_s + prefill + (decode + vocode + post) * scale
     audio_full = B * om.wav_length(full_frames) / cfg.sample_rate
-    return {"value": round(audio_full / t_full, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+    return {"value": round(audio_full / t_full, 4), "unit": "audio-s/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"oracle/model.py (PyTorch eager f32 on bf16-valued weights), {cfg.name}, batch {B}, {args.ref_seconds:g}-s reference clone "
                       f"({om.prefix_embeddings(v).shape[0]}-row prefix prefilled once), {frames} of {full_frames} frames/item decoded + codec decode + "
                       f"post-processing = {t1 - t0:.1f} s of CPU work (conditioning {cond_s:.1f}, prefill {prefill:.1f}, decode {decode:.1f}, codec {vocode:.1f}, post {post:.1f}); "

@@ -223,6 +223,22 @@ __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B ro
 }
 
 // Fused epilogue of one wave's MT x NTT accumulator tiles (shared by k_gemm_tiled and k_conv_win).
+// Every load and store is a BUFFER operation: one resource descriptor per operand in scalar registers - base = the workgroup's
+// tile corner, size = up to the last valid row - and a 32-bit per-lane byte offset.  Rows past M are simply out of range (loads
+// return 0, stores are dropped by the hardware), so there is no row test, no branch and no 64-bit address per element: the
+// per-element `if (row < M)` form compiled to an exec-mask branch per element, serialised the 16 residual loads of a tile behind a
+// `s_waitcnt vmcnt(0)` each, and its address registers spilled the 128 x 128 instantiations into scratch.
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(T* p, int64_t tile_base, int64_t elems) {
+    int64_t bytes = p ? elems * (int64_t)sizeof(T) : 0;          // (an absent operand: an empty buffer nobody touches)
+    if (bytes < 0) bytes = 0;
+    if (bytes > 0x40000000) bytes = 0x40000000;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p + tile_base), 0, (unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ void buf_st_f32(__amdgpu_buffer_rsrc_t r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0); }
+__device__ __forceinline__ void buf_st_b16(__amdgpu_buffer_rsrc_t r, unsigned off, bf16_t v) { __builtin_amdgcn_raw_buffer_store_b16((short)v, r, off, 0, 0); }
+
 template <int MT, int NTT>
 __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[MT][NTT], int64_t m0, int n0, int wm, int wn, int r, int h) {
     // ---- epilogue.  Every option of GemmEpi is uniform over the launch, so each one is tested ONCE per 32x32 accumulator
@@ -230,23 +246,28 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
     // epilogue ~220 instructions per output - several times the cost of the K loop for the codec decoder's short-K convs).
     const GemmEpi& e = g.e;
     const int64_t M = g.a.M, ldc = e.ldc;
+    const int64_t tb = m0 * ldc + n0;                                  // element offset of the workgroup's tile corner (uniform)
+    const int64_t span = (M - m0) * ldc - n0;                          // elements from the corner to the end of the last valid row
+    const unsigned ldc32 = (unsigned)ldc;
+    const __amdgpu_buffer_rsrc_t r_res = tile_rsrc(e.residual, tb, span);
+    const __amdgpu_buffer_rsrc_t r_f32 = tile_rsrc(e.out_f32, tb + (e.split_k > 1 ? (int64_t)blockIdx.z * M * ldc : 0), span);
+    const __amdgpu_buffer_rsrc_t r_bf = tile_rsrc(e.out_bf16, tb, span);
+    const __amdgpu_buffer_rsrc_t r_hi = tile_rsrc(e.out_hi, tb, span), r_lo = tile_rsrc(e.out_lo, tb, span);
+    const __amdgpu_buffer_rsrc_t r2_hi = tile_rsrc(e.out2_hi, tb, span), r2_lo = tile_rsrc(e.out2_lo, tb, span);
+    const __amdgpu_buffer_rsrc_t r2_bf = tile_rsrc(e.out2_bf16, tb, span), r2_f32 = tile_rsrc(e.out2_f32, tb, span);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
             const int n = n0 + (wn * NTT + nt) * 32 + r;
             if (n >= g.N) continue;
-            const int64_t mb = m0 + (wm * MT + mt) * 32 + 4 * h;       // row of accumulator element 0
-            const int64_t ob = mb * ldc + n;
-            // element i sits (i & 3) + 8 * (i >> 2) rows below
+            // element i of the accumulator sits (i & 3) + 8 * (i >> 2) rows below element 0
 #define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
-            bool ok[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ok[i] = mb + RT_ROW(i) < M;
+            const unsigned lo0 = (unsigned)(((wm * MT + mt) * 32 + 4 * h) * ldc32 + (wn * NTT + nt) * 32 + r);   // element offset of element 0 from the corner
+#define RT_OFF(i, bytes) ((lo0 + RT_ROW(i) * ldc32) * (bytes))
             if (e.split_k > 1) {
-                float* slab = e.out_f32 + (int64_t)blockIdx.z * M * ldc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) slab[ob + RT_ROW(i) * ldc] = acc[mt][nt][i];
+                for (int i = 0; i < 16; ++i) buf_st_f32(r_f32, RT_OFF(i, 4), acc[mt][nt][i]);
                 continue;
             }
             // residual rows first, all 16 in flight: the residual usually aliases out_f32 (in-place update), so loads issued
@@ -254,7 +275,7 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
             float res[16];
             if (e.residual) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) res[i] = ok[i] ? e.residual[ob + RT_ROW(i) * ldc] : 0.f;
+                for (int i = 0; i < 16; ++i) res[i] = buf_ld_f32(r_res, RT_OFF(i, 4));
             }
             const float bias = e.bias ? e.bias[n] : 0.f;
             float v[16];
@@ -288,18 +309,19 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
             }
             if (e.out_f32) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_f32[ob + RT_ROW(i) * ldc] = v[i];
+                for (int i = 0; i < 16; ++i) buf_st_f32(r_f32, RT_OFF(i, 4), v[i]);
             }
             if (e.out_bf16) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) if (ok[i]) e.out_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+                for (int i = 0; i < 16; ++i) buf_st_b16(r_bf, RT_OFF(i, 2), f32_to_bf16(v[i]));
             }
             if (e.out_hi) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const bf16_t hi = f32_to_bf16(v[i]);
                     const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
-                    if (ok[i]) { e.out_hi[ob + RT_ROW(i) * ldc] = hi; e.out_lo[ob + RT_ROW(i) * ldc] = lo; }
+                    buf_st_b16(r_hi, RT_OFF(i, 2), hi);
+                    buf_st_b16(r_lo, RT_OFF(i, 2), lo);
                 }
             }
             if (e.out2_hi || e.out2_bf16 || e.out2_f32) {
@@ -316,18 +338,20 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
                     for (int i = 0; i < 16; ++i) {
                         const bf16_t hi = f32_to_bf16(v[i]);
                         const bf16_t lo = f32_to_bf16(v[i] - bf16_to_f32(hi));
-                        if (ok[i]) { e.out2_hi[ob + RT_ROW(i) * ldc] = hi; e.out2_lo[ob + RT_ROW(i) * ldc] = lo; }
+                        buf_st_b16(r2_hi, RT_OFF(i, 2), hi);
+                        buf_st_b16(r2_lo, RT_OFF(i, 2), lo);
                     }
                 }
                 if (e.out2_bf16) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_bf16[ob + RT_ROW(i) * ldc] = f32_to_bf16(v[i]);
+                    for (int i = 0; i < 16; ++i) buf_st_b16(r2_bf, RT_OFF(i, 2), f32_to_bf16(v[i]));
                 }
                 if (e.out2_f32) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) if (ok[i]) e.out2_f32[ob + RT_ROW(i) * ldc] = v[i];
+                    for (int i = 0; i < 16; ++i) buf_st_f32(r2_f32, RT_OFF(i, 4), v[i]);
                 }
             }
+#undef RT_OFF
 #undef RT_ROW
         }
 }
@@ -709,26 +733,31 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
     const bf16_t* __restrict__ hi = reinterpret_cast<const bf16_t*>(g.a.ptr);
     const bf16_t* __restrict__ lo = reinterpret_cast<const bf16_t*>(g.a.ptr_lo);
 
-    // ---- window staging: piece p = tid + 256 i -> (window row p >> 2, 16-B slot p & 3); global row = m0 - halo + row
-    int64_t p_off[NP];
-    bool p_ok[NP];
+    // ---- window staging: piece p = tid + 256 i -> (window row p >> 2, 16-B slot p & 3); global row = m0 - halo + row.
+    // Buffer loads: one resource descriptor per plane in SGPRs (base = the first window row that exists, size = what is left of
+    // the buffer), one 32-bit byte offset per piece in a VGPR, rows before the buffer's start get an offset beyond the size - the
+    // hardware returns zeros for every out-of-range piece.  The 64-bit per-piece addresses of plain global loads (hoisted out of
+    // the chunk loop by the compiler: 12 registers) had pushed this kernel over its 168-VGPR budget (3 waves per SIMD) into
+    // scratch, and the zero fill needed a branch per piece.
+    const int64_t first_row = m0 - halo > 0 ? m0 - halo : 0;          // first window row that exists
+    const int skip = (int)(first_row - (m0 - halo));                  // window rows in front of the buffer
+    int64_t rows_left = g.a.M - first_row;
+    if (rows_left > WR - skip) rows_left = WR - skip;
+    if (rows_left < 0) rows_left = 0;
+    const unsigned win_bytes = (unsigned)(rows_left * Cin * 2);
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(hi + first_row * Cin), 0, win_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(lo + first_row * Cin), 0, win_bytes, 0x00020000);
+    unsigned p_off[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int p = tid + i * 256, row = p >> 2, slot = p & 3;
-        const int64_t gr = m0 - halo + row;
-        p_ok[i] = row < WR && gr >= 0 && gr < g.a.M;
-        p_off[i] = gr * Cin + slot * 8;
+        p_off[i] = (row >= skip && row < WR) ? (unsigned)(((row - skip) * Cin + slot * 8) * 2) : 0x80000000u;
     }
     auto load_win = [&](int cc, s8_t (&a)[NP], s8_t (&l)[NP]) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (p_ok[i]) {
-                a[i] = *reinterpret_cast<const s8_t*>(hi + p_off[i] + cc * 32);
-                l[i] = *reinterpret_cast<const s8_t*>(lo + p_off[i] + cc * 32);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { a[i][j] = 0; l[i][j] = 0; }
-            }
+            a[i] = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, p_off[i] + cc * 64, 0, 0));
+            l[i] = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, p_off[i] + cc * 64, 0, 0));
         }
     };
     auto store_win = [&](int buf, const s8_t (&a)[NP], const s8_t (&l)[NP]) {
@@ -741,21 +770,20 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
             }
         }
     };
-    // ---- B fragments straight from the packed weights: k tile of (tap, chunk, kk) = (tap * Cin + 32 cc) / 16 + kk
+    // ---- B fragments straight from the packed weights: k tile of (tap, chunk, kk) = (tap * Cin + 32 cc) / 16 + kk.
+    // Buffer loads as well: the lane's byte offset inside its column tile is loop-invariant (one VGPR per column tile), the k tile
+    // is a scalar offset, a column tile beyond the matrix reads zeros
     const int nt_base = (n0 >> 5) + wn * NTT;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)g.Wp, 0, (unsigned)((int64_t)g.NT * g.KT * 1024), 0x00020000);
+    unsigned b_off[NTT];
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b_off[nt] = nt_base + nt < g.NT ? (unsigned)(((nt_base + nt) * g.KT * 64 + lane) * 16) : 0x80000000u;
     auto load_b = [&](int tap, int cc, s8_t (&b)[NTT][2]) {
         const int t_k0 = (tap * Cin + cc * 32) >> 4;
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int t_n = nt_base + nt;
-                if (t_n < g.NT) b[nt][kk] = *(reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)t_n * g.KT + t_k0 + kk) * 64 + lane);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[nt][kk][j] = 0;
-                }
-            }
+            for (int kk = 0; kk < 2; ++kk) b[nt][kk] = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[nt], (t_k0 + kk) * 1024, 0));
     };
     // time index of this lane's fragment rows: a tap reaching before the start of its item reads zeros
     int t_row[MT];
