@@ -257,8 +257,9 @@ RT_API int rt_voice_import(rt_model* m, int32_t prefix_len, const void* d_blob, 
 /* n_items may exceed the model's max_batch: the first max_batch items start on the decode rows, the others wait in a queue
  * (in array order - put the longest first) and take over a row as soon as the host has seen its item finish: the new item's
  * prompt suffix is prefilled into the row's KV slot between two frames (continuous batching).  An item's codes depend only
- * on (h_item_ids[i], seed), not on the row, the moment it ran or what it was batched with (bit for bit: tested at the 1.7B
- * shape, tests/test_model_shapes_gpu.py).  Teacher forcing and the logit traces need
+ * on (h_item_ids[i], seed), not on the row, the moment it ran or what it was batched with (bit for bit: tested at the 1.7B and
+ * 0.6B shapes, first waves of fewer than 64, of 416 and of more than 1024 prompt rows - the prompt prefill runs in chunks of
+ * <= 1024 rows on one kernel whose K association equals the <= 64-row kernel's; tests/test_model_shapes_gpu.py).  Teacher forcing and the logit traces need
  * n_items <= max_batch. */
 typedef struct rt_generate_args {
     int32_t n_items;
