@@ -246,6 +246,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 2100) { g_fuse_conv = skinny_variant - 2100; return RT_OK; }            // 2100/2101: the 96-channel conv pairs of the codec decoder as two launches / one
     if (skinny_variant >= 2000) { g_col_max_rows = std::min(64, std::max(1, skinny_variant - 2000)); return RT_OK; }   // 20nn: batches up to nn rows take the column decode path
     if (skinny_variant >= 1900) { g_prefill_mid = skinny_variant - 1900; return RT_OK; }         // 1900/1901: prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid
     if (skinny_variant >= 1800) { g_conv_tall = skinny_variant - 1800; return RT_OK; }           // 1800/1801: 128- / 256-row tiles for the narrow-channel k>1 convs

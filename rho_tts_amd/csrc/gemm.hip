@@ -216,6 +216,10 @@ struct TiledArgs {
     GemmEpi e;
     int kt_per_split;  // in 16-wide k tiles, multiple of 2
     int xcd_order = 0;   // 1: XCD-aware tile order (see k_gemm_tiled)
+    // k_conv_win<..., FUSE = true>: the 1x1 conv behind this conv's activation runs in the same launch (see the kernel)
+    const bf16_t* Wp2 = nullptr;
+    int NT2 = 0, KT2 = 0, N2 = 0;
+    GemmEpi e2;
 };
 
 __device__ __forceinline__ int lds_a_off(int row, int slot) {  // bytes; 64-B rows, 16-B slots XOR-swizzled by row/4
@@ -240,12 +244,18 @@ __device__ __forceinline__ void buf_st_f32(__amdgpu_buffer_rsrc_t r, unsigned of
 __device__ __forceinline__ void buf_st_b16(__amdgpu_buffer_rsrc_t r, unsigned off, bf16_t v) { __builtin_amdgcn_raw_buffer_store_b16((short)v, r, off, 0, 0); }
 
 template <int MT, int NTT>
+__device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int N, f16_t (&acc)[MT][NTT], int64_t m0, int n0, int row_blk0, int wn, int r, int h);
+template <int MT, int NTT>
 __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[MT][NTT], int64_t m0, int n0, int wm, int wn, int r, int h) {
+    tile_epilogue_e<MT, NTT>(g.e, g.a.M, g.N, acc, m0, n0, wm * MT, wn, r, h);
+}
+// row_blk0: index (in 32-row blocks from m0) of the wave's first accumulator tile
+template <int MT, int NTT>
+__device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int N, f16_t (&acc)[MT][NTT], int64_t m0, int n0, int row_blk0, int wn, int r, int h) {
     // ---- epilogue.  Every option of GemmEpi is uniform over the launch, so each one is tested ONCE per 32x32 accumulator
     // tile with the 16-element loops inside (tested per element, the option branches and 64-bit index arithmetic made the
     // epilogue ~220 instructions per output - several times the cost of the K loop for the codec decoder's short-K convs).
-    const GemmEpi& e = g.e;
-    const int64_t M = g.a.M, ldc = e.ldc;
+    const int64_t ldc = e.ldc;
     const int64_t tb = m0 * ldc + n0;                                  // element offset of the workgroup's tile corner (uniform)
     const int64_t span = (M - m0) * ldc - n0;                          // elements from the corner to the end of the last valid row
     const unsigned ldc32 = (unsigned)ldc;
@@ -260,10 +270,10 @@ __device__ __forceinline__ void tile_epilogue(const TiledArgs& g, f16_t (&acc)[M
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
             const int n = n0 + (wn * NTT + nt) * 32 + r;
-            if (n >= g.N) continue;
+            if (n >= N) continue;
             // element i of the accumulator sits (i & 3) + 8 * (i >> 2) rows below element 0
 #define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
-            const unsigned lo0 = (unsigned)(((wm * MT + mt) * 32 + 4 * h) * ldc32 + (wn * NTT + nt) * 32 + r);   // element offset of element 0 from the corner
+            const unsigned lo0 = (unsigned)(((row_blk0 + mt) * 32 + 4 * h) * ldc32 + (wn * NTT + nt) * 32 + r);   // element offset of element 0 from the corner
 #define RT_OFF(i, bytes) ((lo0 + RT_ROW(i) * ldc32) * (bytes))
             if (e.split_k > 1) {
 #pragma unroll
@@ -704,15 +714,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
 // waves all need the SAME weight fragments (the waves split the rows, not the 96 columns) - with 3 workgroups per CU the
 // per-CU vector L1 (64 B/clk) then moves as many weight bytes per tap as the SIMDs spend cycles on its MFMAs; twice the
 // rows per weight fragment halves that.
-template <int WGM, int WGN, int MT, int NTT>
+//
+// FUSE (the 96-channel residual units of the codec decoder, where both convs are bound by HBM traffic, not by the matrix
+// cores): the unit's 1x1 conv runs in the SAME launch.  A wave holds all 96 output channels of its rows (WGN = 1), so after
+// the K loop it applies bias + SnakeBeta, writes the hi / lo bf16 planes of the result - exactly what the unfused form stores
+// to HBM for the next launch - to a private LDS region in A-operand order, multiplies by the 96 x 96 weight of the 1x1 conv
+// (fragments from L2) and runs that conv's epilogue (bias, residual, the next unit's SnakeBeta planes).  Saved per element:
+// the 4-byte write and the 4-byte re-read of the intermediate planes (24 -> 16 bytes of HBM traffic per element and unit) and
+// one launch.
+template <int WGM, int WGN, int MT, int NTT, bool FUSE = false>
 __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win(TiledArgs g) {
     static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(!FUSE || (WGN == 1 && NTT == 3), "the fused 1x1 conv needs every output channel of a row in one wave");
     constexpr int BMT = WGM * MT * 32;
     constexpr int WIN_ROWS = BMT + 64;
     constexpr int NP = (WIN_ROWS * 4 + 255) / 256;        // 16-B window pieces per thread and plane
     constexpr int BNT = WGN * NTT * 32;
     constexpr int PLANE = WIN_ROWS * 64;                  // bytes per plane and stage
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * PLANE];
+    constexpr int F_ROWB = NTT * 32 * 2 + 16;             // fused form: bytes per row of a wave's staged tile (96 bf16 + padding)
+    constexpr int F_WAVE = 2 * 32 * F_ROWB;               // ... hi and lo planes of 32 rows
+    constexpr int LDS_BYTES = (FUSE && 4 * F_WAVE > 2 * 2 * PLANE) ? 4 * F_WAVE : 2 * 2 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WGN, wn = w % WGN;
     const int r = lane & 31, h = lane >> 5;
@@ -849,7 +871,54 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
         if (more) store_win(buf ^ 1, ra, rl);
         __syncthreads();
     }
-    tile_epilogue<MT, NTT>(g, acc, m0, n0, wm, wn, r, h);
+    if constexpr (!FUSE) {
+        tile_epilogue<MT, NTT>(g, acc, m0, n0, wm, wn, r, h);
+    } else {
+        // (every wave is past the last barrier of the K loop: the window buffers are free, each wave takes its own region)
+        unsigned char* my = lds + w * F_WAVE;
+        const GemmEpi& e = g.e;
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)g.Wp2, 0, (unsigned)((int64_t)g.NT2 * g.KT2 * 1024), 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            // 1. this conv's epilogue (bias, SnakeBeta) into LDS as hi / lo planes, [row][channel]
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const int n = nt * 32 + r;
+                const float bias = e.bias ? e.bias[n] : 0.f, sa = e.snake_a[n], sib = e.snake_ib[n];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[mt][nt][i] + bias;
+                    const float sn = __sinf(v * sa);
+                    v = v + sib * sn * sn;
+                    const bf16_t hi = f32_to_bf16(v);
+                    const bf16_t lo = f32_to_bf16(v - bf16_to_f32(hi));
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    *reinterpret_cast<bf16_t*>(my + row * F_ROWB + n * 2) = hi;
+                    *reinterpret_cast<bf16_t*>(my + 32 * F_ROWB + row * F_ROWB + n * 2) = lo;
+                }
+            }
+            // (the same wave reads what it wrote: a wave's LDS operations complete in order)
+            // 2. the 1x1 conv: [32 rows][96] x W2^T, hi + lo planes against each weight fragment
+            f16_t acc2[1][NTT];
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[0][nt][i] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < NTT * 2; ++k2) {
+                const s8_t a_hi = *reinterpret_cast<const s8_t*>(my + r * F_ROWB + (k2 * 16 + h * 8) * 2);
+                const s8_t a_lo = *reinterpret_cast<const s8_t*>(my + 32 * F_ROWB + r * F_ROWB + (k2 * 16 + h * 8) * 2);
+#pragma unroll
+                for (int nt = 0; nt < NTT; ++nt) {
+                    const s8_t b = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (unsigned)(((nt * g.KT2 + k2) * 64 + lane) * 16), 0, 0));
+                    acc2[0][nt] = mfma32(a_hi, b, acc2[0][nt]);
+                    acc2[0][nt] = mfma32(a_lo, b, acc2[0][nt]);
+                }
+            }
+            // 3. the 1x1 conv's epilogue on this wave's 32 rows
+            tile_epilogue_e<1, NTT>(g.e2, g.a.M, g.N2, acc2, m0, 0, wm * MT + mt, 0, r, h);
+        }
+    }
 }
 
 }  // namespace
@@ -987,7 +1056,17 @@ int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float
     return RT_OK;
 }
 
-int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e) {
+int g_fuse_conv = 1;            // 1: a 96-channel k>1 conv and the 1x1 conv behind its activation run as one launch (launch_conv_pair)
+
+// a k > 1 conv with SnakeBeta whose hi / lo output planes feed only the 1x1 conv (w2, e2): both in one launch when the first
+// conv's workgroup tile holds every output channel (96 channels, the LDS-window kernel) - else two launches through the planes
+bool conv_pair_fusable(const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW& w2) {
+    return g_fuse_conv && g_conv_win && g_tile96 && w.N == 96 && w2.N == 96 && w2.K == 96 && w2.Kp == 96 && e.act == ACT_SNAKE && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 &&
+           a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out && a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 &&
+           a.M % a.rows_out == 0;
+}
+
+int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW* w2, const GemmEpi* e2) {
     if (a.M <= 0) return RT_OK;
     if (a.Cin % 8 || (int64_t)a.Cin * a.taps != w.K)
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: A has taps=%d Cin=%d but W has K=%d", a.taps, a.Cin, w.K);
@@ -1017,6 +1096,16 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e)
     if ((e.out_hi && !e.out_lo) || (e.out2_hi && (!e.out2_lo || (e.act2 != ACT_ELU && (!e.snake2_a || !e.snake2_ib)))) ||
         ((e.out_hi || e.out2_hi) && e.split_k > 1))
         return rt_fail(ctx, RT_ERR_INVALID, "gemm: incomplete hi/lo plane output");
+    if (w2) {           // fused conv pair: only the form conv_pair_fusable() describes
+        if (!e2 || !conv_win || !narrow || ny != 1 || w.N != 96 || w2->N != 96 || w2->K != 96 || e.act != ACT_SNAKE || !e.snake_a || !e.snake_ib ||
+            e2->split_k != 1 || e2->ldc < 96)
+            return rt_fail(ctx, RT_ERR_INVALID, "gemm: this conv pair cannot be fused (96 channels, k > 1 conv with SnakeBeta, then a 96 x 96 1x1 conv)");
+        g.Wp2 = w2->data; g.NT2 = w2->Np / 32; g.KT2 = w2->Kp / 16; g.N2 = w2->N; g.e2 = *e2;
+        if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3, true>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3, true>), grid, dim3(256), 0, ctx->stream, g);
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    }
     if (conv_win) {
         if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3>), grid, dim3(256), 0, ctx->stream, g);
         else if (narrow) hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);

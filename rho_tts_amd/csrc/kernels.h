@@ -68,7 +68,11 @@ size_t packed_bytes(int N, int K);
 int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
 size_t packed16_bytes(int N, int K);
 int launch_pack_weight16(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d_dst, PackedW* out);
-int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e);
+// w2 / e2 (optional): the 1x1 conv behind this conv's SnakeBeta, fused into the same launch (conv_pair_fusable must hold; e's
+// out_hi / out_lo planes are then not written)
+int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW* w2 = nullptr, const GemmEpi* e2 = nullptr);
+bool conv_pair_fusable(const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW& w2);
+extern int g_fuse_conv;
 // prompt-prefill GEMM (65..1024 rows): out[M][N] f32 = A[M][K] bf16 . W^T, whole K per 64 x 64 tile, final sums (no slabs)
 extern int g_prefill_mid;
 bool gemm_mid_ok(int M, const PackedW& w);

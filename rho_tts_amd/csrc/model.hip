@@ -1968,13 +1968,21 @@ int rt_code2wav(rt_model* m, int32_t n_items, int32_t t_max, const int32_t* h_co
             a.rows_out = (int)To; a.rows_in = (int)To;
             GemmEpi e; e.bias = VEC(m, u + ".c1_b"); e.act = ACT_SNAKE; e.snake_a = VEC(m, u + ".a2"); e.snake_ib = VEC(m, u + ".ib2");
             e.out_hi = s2.hi; e.out_lo = s2.lo; e.ldc = cout;
-            RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e));
             GemmA a2; a2.ptr = s2.hi; a2.ptr_lo = s2.lo; a2.split = 1; a2.M = rows; a2.Cin = cout;
             GemmEpi e2; e2.bias = VEC(m, u + ".c2_b"); e2.residual = xr; e2.out_f32 = xr; e2.out2_hi = s1.hi; e2.out2_lo = s1.lo; e2.ldc = cout;
             if (j < 2) { e2.snake2_a = VEC(m, bn + ".u" + std::to_string(j + 1) + ".a1"); e2.snake2_ib = VEC(m, bn + ".u" + std::to_string(j + 1) + ".ib1"); }
             else if (i + 1 < c.n_upsample_rates) { e2.snake2_a = VEC(m, "codec.b" + std::to_string(i + 1) + ".sa"); e2.snake2_ib = VEC(m, "codec.b" + std::to_string(i + 1) + ".sib"); }
             else { e2.snake2_a = VEC(m, "codec.fin_a"); e2.snake2_ib = VEC(m, "codec.fin_ib"); }
-            RT_TRY(launch_gemm(ctx, a2, PW(m, u + ".c2"), e2));
+            // NOTE: the fused form writes s1 (the NEXT unit's operand planes) while other workgroups still read s1 as THIS unit's
+            // input window, so it needs a second pair of planes to write to: s1 and s2 swap roles from unit to unit
+            if (conv_pair_fusable(a, PW(m, u + ".c1"), e, PW(m, u + ".c2"))) {
+                e2.out2_hi = s2.hi; e2.out2_lo = s2.lo;
+                RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e, &PW(m, u + ".c2"), &e2));
+                std::swap(s1, s2);
+            } else {
+                RT_TRY(launch_gemm(ctx, a, PW(m, u + ".c1"), e));
+                RT_TRY(launch_gemm(ctx, a2, PW(m, u + ".c2"), e2));
+            }
         }
         s_in = s1;
         Tc = To;

@@ -140,6 +140,17 @@ def test_code2wav_at_real_codec_dimensions(ctx):
         # (no split or tile choice in the decoder depends on the number of rows)
         for c, w in zip(codes, wavs):
             assert torch.equal(nm.code2wav([c])[0], w)
+        # the 96-channel residual units run their k = 7 conv and 1x1 conv as ONE launch (k_conv_win<..., FUSE>); as two launches
+        # through hi / lo planes in HBM (rt_debug_tune 2100) the same planes are multiplied in another MFMA order: float rounding apart
+        nm.lib.rt_debug_tune(2100, 0)
+        try:
+            two = nm.code2wav(codes)
+        finally:
+            nm.lib.rt_debug_tune(2101, 0)
+        for a, b in zip(two, wavs):
+            d = float((a - b).abs().max())
+            print(f"\nfused vs two-launch conv pairs: max diff {d:.2e}")
+            assert d < 2e-5 and not torch.equal(a, torch.zeros_like(a))
     finally:
         nm.close()
 
