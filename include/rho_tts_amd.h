@@ -390,6 +390,13 @@ RT_API int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, 
                                     const float* d_q_norm_w, const float* d_k_norm_w, float eps, const float* d_cos, const float* d_sin,
                                     const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t pos_add, void* d_k, void* d_v,
                                     int32_t slots, int32_t max_pos, int32_t prefix_slot, int32_t prefix_len, void* d_out_bf16);
+/* Prompt-prefill attention behind a shared prefix: q [M][heads][d] f32 (normed, roped), row r = sequence slot row_slot[r] at position
+ * row_pos[r], whose K / V rows up to that position are already in the caches; positions < prefix_len are read from prefix_slot.
+ * mode 0: the vector-unit kernel, 1: the matrix-core form the model uses for prompt rows (head_dim 128, 2 query heads per kv head,
+ * prefix_len >= 64).  out [M][heads*d] bf16. */
+RT_API int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
+                                      const int32_t* d_row_slot, const int32_t* d_row_pos, const void* d_k, const void* d_v, int32_t slots,
+                                      int32_t max_pos, int32_t prefix_slot, int32_t prefix_len, int32_t mode, void* d_out_bf16);
 /* One draw per row: logits [M][V] f32 -> tokens [M].  item ids 0..M-1. */
 RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed,
                            int32_t frame, int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out);
@@ -407,7 +414,8 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   20nn batches of up to nn rows (default 64) decode on the column-owner path, larger ones on the legacy split-K path |
  *   1900/1901/1902/1903 prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid (automatic, 64 x 64, 128 x 128 tiles) |
  *   1800/1801/1802 narrow-channel (96 / 192) k>1 convs on 128-row tiles / 256-row tiles for long inputs / 256-row tiles always |
- *   2100/2101 the codec decoder's 96-channel residual units as two launches (k = 7 conv, 1x1 conv) / one fused launch
+ *   2100/2101 the codec decoder's 96-channel residual units as two launches (k = 7 conv, 1x1 conv) / one fused launch |
+ *   2200/2201 prompt-prefill attention behind a shared voice prefix on the vector unit / on the matrix cores
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);

@@ -83,6 +83,7 @@ def declare(lib: C.CDLL) -> None:
     f32 = C.c_float
     lib.rt_debug_gemm_col.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, f32, vp, vp, vp, vp, vp, vp, vp]
     lib.rt_debug_attention_fused.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.rt_debug_attention_prefill.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.rt_debug_sample.argtypes = [vp, vp, i32, i32, C.POINTER(RtSampling), C.c_uint64, i32, i32, i32, i32, vp, vp]
 
 

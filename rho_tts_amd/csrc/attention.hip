@@ -283,6 +283,10 @@ int attention_any(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, i
 int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, int head_dim, const int32_t* row_slot,
                      const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled,
                      float* out_f32) {
+    // prompt rows behind a shared voice prefix: the matrix-core form (attention_mfma.hip).  The choice depends on the model and
+    // the voice only, never on M: a text gets the same bits prefilled alone, in the first wave or at a hand-over
+    if (!frame_ptr && !out_tiled && !out_f32 && out && attention_prefill_mfma_ok(heads, kv_heads, head_dim, window, kv))
+        return launch_attention_prefill_mfma(ctx, q, M, heads, kv_heads, row_slot, row_pos, pos_add, kv, layer, out);
     FusedArgs f{};
     f.frame_ptr = frame_ptr;
     f.out_tiled = out_tiled;

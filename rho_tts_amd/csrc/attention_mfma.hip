@@ -26,11 +26,21 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
 }
 
-constexpr int D = 128, REP = 2, ROWS = 4, NW = 16, QR = ROWS * REP;     // 8 live query vectors of the 16 MFMA rows
+constexpr int D = 128, REP = 2;
 constexpr int LPP = D / 8, PPW = 64 / LPP;                              // suffix part: lanes per position, positions per wave step
+// Two instantiations:
+//   decode  <ROWS 4, 16 waves, PREFILL false>: the fused decode step described above (4 rows x 2 heads = 8 of the 16 MFMA columns)
+//   prefill <ROWS 8,  8 waves, PREFILL true>: PROMPT rows (the texts' suffixes behind a shared voice prefix; q already normed /
+//           roped and K / V already appended by k_qkv_post): 8 rows x 2 heads fill the 16 MFMA columns, one wave per row takes
+//           the row's own positions.  k_attention re-reads the 235 KB of prefix K / V per (row, kv head) from L2 - 416 suffix
+//           rows x 8 heads x 28 layers per batch; here it is read once per 8 rows and multiplied on the matrix cores.
+//           A row's result depends on nothing but the row: the prefix part is one MFMA column per query vector with the key
+//           blocks dealt to the waves in a fixed order, the own part is one wave - so a text prefilled alone, among 400 rows or at
+//           a hand-over gets the same bits (the property continuous batching rests on), whatever 8-row block it falls into.
 
 struct MfmaAttnArgs {
-    const float* qkv; int M, heads, kv_heads;
+    const float* qkv;                 // decode: raw projections [M][(heads + 2 kv) D]; prefill: q [M][heads][D], normed and roped
+    int M, heads, kv_heads;
     const int32_t* row_slot; const int32_t* row_pos; int pos_add;
     bf16_t* kc; bf16_t* vc; int max_pos;
     const bf16_t* kt;                 // fragment-tiled prefix K / V of this layer: [kv_heads][vt_stride]
@@ -40,12 +50,16 @@ struct MfmaAttnArgs {
     const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len;
 };
 
+template <int ROWS, int NW, bool PREFILL>
 __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
+    constexpr int QR = ROWS * REP;                                         // live query vectors of the 16 MFMA columns
+    constexpr int WPR = NW / ROWS;                                         // waves per row for the rows' own positions
+    static_assert(QR <= 16 && NW % ROWS == 0 && (PREFILL || NW == 4 * ROWS), "wave layout");
     constexpr int QP = D + 8;                                              // row pitch 272 B: the 16 rows of a b128 fragment read land on distinct banks
     __shared__ __attribute__((aligned(16))) bf16_t sq_hi[16][QP];         // Q (scaled), bf16 hi / lo planes, rows >= QR zero
     __shared__ __attribute__((aligned(16))) bf16_t sq_lo[16][QP];
     __shared__ float sq_f[QR][D];                                          // the same in float32 for the suffix part
-    __shared__ __attribute__((aligned(16))) bf16_t s_kv[ROWS][2][D];       // the appended K / V rows (as rounded for the cache)
+    __shared__ __attribute__((aligned(16))) bf16_t s_kv[PREFILL ? 1 : ROWS][2][D];   // the appended K / V rows (as rounded for the cache); decode only
     __shared__ float p_m[NW][QR], p_l[NW][QR];                             // prefix partials per wave
     __shared__ float p_acc[NW][QR][D];
     __shared__ float s_part[NW][REP][LPP][10];                             // suffix partials per wave
@@ -77,7 +91,24 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
         for (int dt = 0; dt < 8; ++dt) vf[dt] = vtp[((int64_t)blk * 8 + dt) * 64];
     }
     __syncthreads();
-    {
+    if constexpr (PREFILL) {
+        // query vector qi = rr * REP + head of the block's rows: one wave per vector and turn; K / V are in the cache already
+        for (int qi = w; qi < QR; qi += NW) {
+            const int rr = qi / REP, vec = qi % REP, row = r0 + rr;
+            constexpr int half = D / 2;
+            if (row < g.M) {
+                if (vec == 0 && lane == 0) s_hi[rr] = g.row_pos[row] + g.pos_add + frame;
+                const float* qp = g.qkv + ((int64_t)row * heads + kh * REP + vec) * D;
+                const float qa = qp[lane] * scale, qb = qp[lane + half] * scale;
+                sq_f[qi][lane] = qa; sq_f[qi][lane + half] = qb;
+                const bf16_t ha = f32_to_bf16(qa), hb = f32_to_bf16(qb);
+                sq_hi[qi][lane] = ha; sq_hi[qi][lane + half] = hb;
+                sq_lo[qi][lane] = f32_to_bf16(qa - bf16_to_f32(ha)); sq_lo[qi][lane + half] = f32_to_bf16(qb - bf16_to_f32(hb));
+            } else if (vec == 0 && lane == 0) {
+                s_hi[rr] = -1;
+            }
+        }
+    } else {
         const int rr = w >> 2, vec = w & 3;                 // local row, vector: 0,1 = the two query heads, 2 = K, 3 = V
         const int row = r0 + rr;
         if (row < g.M) {
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
 
     // ---------------------------------------------------------------- C: the rows' own positions [Lp, hi] on the vector unit
     {
-        const int rr = w >> 2, sw = w & 3;                   // four waves per local row
+        const int rr = w / WPR, sw = w % WPR;                // WPR waves per local row
         const int hi = s_hi[rr];
         const int sub = lane % LPP, pg = lane / LPP;
         float m[REP], l[REP], acc[REP][8];
@@ -220,15 +251,19 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
             for (int r = 0; r < REP; ++r)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qr[r][j] = sq_f[rr * REP + r][sub * 8 + j];
-            constexpr int U = 4;                             // positions in flight per lane: 4 waves x 4 positions x 4 = 64 suffix rows per batch
-            for (int p0 = (Lp <= hi + 1 ? Lp : hi + 1) + sw * PPW + pg; p0 <= hi; p0 += 4 * PPW * U) {
+            constexpr int U = 4;                             // positions in flight per lane: WPR waves x 4 positions x 4 per batch
+            for (int p0 = (Lp <= hi + 1 ? Lp : hi + 1) + sw * PPW + pg; p0 <= hi; p0 += WPR * PPW * U) {
                 u4_t kk[U], vv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int p = p0 + u * 4 * PPW;
-                    if (p >= hi) {                           // the row this launch appends (and clamped slots past it): from LDS, not through global memory
-                        kk[u] = *reinterpret_cast<const u4_t*>(&s_kv[rr][0][sub * 8]);
-                        vv[u] = *reinterpret_cast<const u4_t*>(&s_kv[rr][1][sub * 8]);
+                    const int p = p0 + u * WPR * PPW;
+                    if (PREFILL) {                           // every own row sits in the cache (k_qkv_post ran first); slots past the row re-read it
+                        const int pc = p <= hi ? p : hi;
+                        kk[u] = *reinterpret_cast<const u4_t*>(kb + (int64_t)pc * D);
+                        vv[u] = *reinterpret_cast<const u4_t*>(vb + (int64_t)pc * D);
+                    } else if (p >= hi) {                    // the row this launch appends (and clamped slots past it): from LDS, not through global memory
+                        kk[u] = *reinterpret_cast<const u4_t*>(&s_kv[PREFILL ? 0 : rr][0][sub * 8]);
+                        vv[u] = *reinterpret_cast<const u4_t*>(&s_kv[PREFILL ? 0 : rr][1][sub * 8]);
                     } else {
                         kk[u] = *reinterpret_cast<const u4_t*>(kb + (int64_t)p * D);
                         vv[u] = *reinterpret_cast<const u4_t*>(vb + (int64_t)p * D);
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int p = p0 + u * 4 * PPW;
+                    const int p = p0 + u * WPR * PPW;
                     float kf2[8], vf2[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -295,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
         const int nb_w = n_blk < NW ? n_blk : NW;             // waves that saw a prefix block
         for (int ww = 0; ww < nb_w; ++ww) mn = fmaxf(mn, p_m[ww][qi]);
 #pragma unroll
-        for (int sw = 0; sw < 4; ++sw) mn = fmaxf(mn, s_part[rr * 4 + sw][r][sb][0]);
+        for (int sw = 0; sw < WPR; ++sw) mn = fmaxf(mn, s_part[rr * WPR + sw][r][sb][0]);
         float lt = 0.f, at = 0.f;
         for (int ww = 0; ww < nb_w; ++ww) {
             const float c = __expf(p_m[ww][qi] - mn);
@@ -303,10 +338,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
             at += p_acc[ww][qi][d] * c;
         }
 #pragma unroll
-        for (int sw = 0; sw < 4; ++sw) {
-            const float c = __expf(s_part[rr * 4 + sw][r][sb][0] - mn);
-            lt += s_part[rr * 4 + sw][r][sb][1] * c;
-            at += s_part[rr * 4 + sw][r][sb][2 + j] * c;
+        for (int sw = 0; sw < WPR; ++sw) {
+            const float c = __expf(s_part[rr * WPR + sw][r][sb][0] - mn);
+            lt += s_part[rr * WPR + sw][r][sb][1] * c;
+            at += s_part[rr * WPR + sw][r][sb][2 + j] * c;
         }
         const int kcol = (kh * REP + r) * D + d;
         const int64_t oo = g.out_tiled ? tile_off(row, kcol, heads * D) : (int64_t)row * heads * D + kcol;
@@ -352,7 +387,26 @@ int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads
     g.kt = kv.kt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt = kv.vt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt_stride = kv.vt_stride;
     g.out = out; g.qw = q_norm_w; g.kw = k_norm_w; g.eps = eps; g.cosT = rope_cos; g.sinT = rope_sin; g.frame_ptr = frame_ptr; g.out_tiled = out_tiled;
     g.prefix_slot = kv.prefix_slot; g.prefix_len = kv.prefix_len;
-    hipLaunchKernelGGL(k_attn_prefix_mfma, dim3(kv_heads, (M + ROWS - 1) / ROWS), dim3(NW * 64), 0, ctx->stream, g);
+    hipLaunchKernelGGL((k_attn_prefix_mfma<4, 16, false>), dim3(kv_heads, (M + 3) / 4), dim3(16 * 64), 0, ctx->stream, g);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// prompt rows behind a shared prefix (see the kernel's header): the same preconditions as the decode form but q comes prepared
+int g_prefill_attn_mfma = 1;
+bool attention_prefill_mfma_ok(int heads, int kv_heads, int head_dim, int window, const KvCache& kv) {
+    return g_prefill_attn_mfma && head_dim == D && kv.head_dim == D && heads == REP * kv_heads && window <= 0 && !kv.k_lo && kv.prefix_slot >= 0 &&
+           kv.vt_prefix && kv.kt_prefix && kv.prefix_len >= 64 && kv.tiles_len == kv.prefix_len && (kv.prefix_len + 31) / 32 * 4096 <= kv.vt_stride;
+}
+int launch_attention_prefill_mfma(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
+                                  const KvCache& kv, int layer, bf16_t* out) {
+    MfmaAttnArgs g;
+    g.qkv = q; g.M = M; g.heads = heads; g.kv_heads = kv_heads; g.row_slot = row_slot; g.row_pos = row_pos; g.pos_add = pos_add;
+    g.kc = kv.k + layer * kv.layer_stride(); g.vc = kv.v + layer * kv.layer_stride(); g.max_pos = kv.max_pos;
+    g.kt = kv.kt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt = kv.vt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt_stride = kv.vt_stride;
+    g.out = out; g.qw = nullptr; g.kw = nullptr; g.eps = 0.f; g.cosT = nullptr; g.sinT = nullptr; g.frame_ptr = nullptr; g.out_tiled = 0;
+    g.prefix_slot = kv.prefix_slot; g.prefix_len = kv.prefix_len;
+    hipLaunchKernelGGL((k_attn_prefix_mfma<8, 8, true>), dim3(kv_heads, (M + 7) / 8), dim3(8 * 64), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -365,5 +419,6 @@ int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len) {
                            kv.kv_heads, kv.max_pos, kv.prefix_slot_alloc, prefix_len, kv.kt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride,
                            kv.vt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride, kv.vt_stride);
     RT_HIP(ctx, hipGetLastError());
+    kv.tiles_len = prefix_len;
     return RT_OK;
 }

@@ -225,6 +225,44 @@ int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t
     return rc;
 }
 
+// Prompt-prefill attention behind a shared prefix slot (q prepared, K / V rows already in the caches): mode 0 = the vector-unit
+// kernel (k_attention), 1 = the matrix-core form the model uses for prompt rows (attention_mfma.hip, head_dim 128, 2 query heads per
+// kv head, prefix of >= 64 rows)
+int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim, const int32_t* d_row_slot,
+                               const int32_t* d_row_pos, const void* d_k, const void* d_v, int32_t slots, int32_t max_pos, int32_t prefix_slot,
+                               int32_t prefix_len, int32_t mode, void* d_out_bf16) {
+    if (!ctx || !d_q || !d_row_slot || !d_row_pos || !d_k || !d_v || !d_out_bf16 || M < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_prefill: null argument");
+    if (prefix_slot < 0 || prefix_slot >= slots || prefix_len < 1 || prefix_len > max_pos) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_prefill: bad prefix");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    KvCache kv;
+    kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
+    kv.prefix_slot = prefix_slot; kv.prefix_len = prefix_len;
+    bf16_t* vt = nullptr;
+    const int saved = g_prefill_attn_mfma;
+    g_prefill_attn_mfma = mode ? 1 : 0;
+    if (mode) {
+        if (head_dim != 128) { g_prefill_attn_mfma = saved; return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_debug_attention_prefill: the matrix-core form needs head_dim 128"); }
+        kv.vt_stride = (prefix_len + 31) / 32 * 4096;
+        kv.prefix_slot_alloc = prefix_slot;
+        RT_HIP(ctx, hipMalloc((void**)&vt, (size_t)2 * kv_heads * kv.vt_stride * 2));
+        kv.kt_prefix = vt;
+        kv.vt_prefix = vt + (size_t)kv_heads * kv.vt_stride;
+        const int rt = launch_transpose_prefix_v(ctx, kv, prefix_len);
+        if (rt) { (void)hipFree(vt); g_prefill_attn_mfma = saved; return rt; }
+        if (!attention_prefill_mfma_ok(heads, kv_heads, head_dim, 0, kv)) {
+            (void)hipFree(vt); g_prefill_attn_mfma = saved;
+            return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_debug_attention_prefill: shape not served by the matrix-core form");
+        }
+    }
+    const int rc = launch_attention(ctx, d_q, M, heads, kv_heads, head_dim, d_row_slot, d_row_pos, 0, 0, kv, 0, (bf16_t*)d_out_bf16);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    g_prefill_attn_mfma = saved;
+    if (vt) (void)hipFree(vt);
+    RT_HIP(ctx, se);
+    return rc;
+}
+
 int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed, int32_t frame,
                     int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out) {
     if (!ctx || !d_logits || !sp || !d_out || M < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_sample: null argument");
@@ -246,6 +284,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 2200) { g_prefill_attn_mfma = skinny_variant - 2200; return RT_OK; }    // 2200/2201: prompt attention behind a shared prefix on the vector unit / matrix cores
     if (skinny_variant >= 2100) { g_fuse_conv = skinny_variant - 2100; return RT_OK; }            // 2100/2101: the 96-channel conv pairs of the codec decoder as two launches / one
     if (skinny_variant >= 2000) { g_col_max_rows = std::min(64, std::max(1, skinny_variant - 2000)); return RT_OK; }   // 20nn: batches up to nn rows take the column decode path
     if (skinny_variant >= 1900) { g_prefill_mid = skinny_variant - 1900; return RT_OK; }         // 1900/1901: prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid

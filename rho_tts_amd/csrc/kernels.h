@@ -182,6 +182,7 @@ struct KvCache {
     bf16_t* vt_prefix = nullptr;
     int vt_stride = 0;              // elements per (layer, kv head) = ceil(max_pos / 32) * 4096
     int prefix_slot_alloc = -1;     // the slot that holds the prefix (fixed per model; prefix_slot above is switched on / off around its prefill)
+    int tiles_len = -1;             // prefix length kt_prefix / vt_prefix were built for (-1: stale)
     size_t layer_stride() const { return (size_t)slots * kv_heads * max_pos * head_dim; }
 };
 // qkv slabs [S][M][(heads+2*kv_heads)*d] -> q (f32 [M][heads][d], normed + roped), k/v appended to the cache
@@ -210,6 +211,11 @@ int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads
                                  const float* rope_cos, const float* rope_sin, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
                                  const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled);
 int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len);
+// prompt rows (q prepared by launch_qkv_post, K / V appended) behind a shared prefix on the matrix cores: bf16 out [M][heads * d]
+extern int g_prefill_attn_mfma;
+bool attention_prefill_mfma_ok(int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
+int launch_attention_prefill_mfma(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
+                                  const KvCache& kv, int layer, bf16_t* out);
 
 // ------------------------------------------------------------------------------ embedding kernels
 // out[m][:] = sum_j table_j[idx[m][j]][:]  (+ add_vec) ; tables are bf16 [V_j][H]; idx < 0 skips the term.

@@ -882,7 +882,14 @@ static int set_voice_impl(rt_model* m, int32_t n_rows, const int32_t* h_text_ids
     bf16_t* hn = nullptr;
     RT_TRY(pool_arr(m, (size_t)n_rows * H, &hn));
     RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr));
-    m->prefix_tiles_valid = false;     // (fragment-tiled prefix copies are only built when the matrix-core attention is switched on: rt_generate)
+    // fragment-tiled copies of the prefix K / V for the matrix-core attention of the prompt prefills (and of the decode step when
+    // that form is switched on): once per voice
+    m->prefix_tiles_valid = false;
+    m->talker.kv.tiles_len = -1;
+    if (c.talker.head_dim == 128 && m->talker.kv.kt_prefix) {
+        RT_TRY(launch_transpose_prefix_v(ctx, m->talker.kv, n_rows));
+        m->prefix_tiles_valid = true;
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->prefix_len = n_rows;
     pool_release_all(m);
@@ -1080,7 +1087,14 @@ static int voice_blob(rt_model* m, void* d_blob, int64_t bytes, int to_blob, int
     hipLaunchKernelGGL(k_kv_blob, dim3(d.layers * d.kv_heads, 2), dim3(256), 0, ctx->stream, kv.k, kv.v, (int64_t)kv.layer_stride(), d.layers,
                        d.kv_heads, kv.max_pos, d.head_dim, m->prefix_slot(), prefix_len, (bf16_t*)d_blob, to_blob);
     RT_HIP(ctx, hipGetLastError());
-    if (!to_blob) m->prefix_tiles_valid = false;
+    if (!to_blob) {
+        m->prefix_tiles_valid = false;
+        m->talker.kv.tiles_len = -1;
+        if (d.head_dim == 128 && kv.kt_prefix) {
+            RT_TRY(launch_transpose_prefix_v(ctx, kv, prefix_len));
+            m->prefix_tiles_valid = true;
+        }
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!to_blob) m->prefix_len = prefix_len;
     return RT_OK;

@@ -185,3 +185,20 @@ def test_float32_codebooks_stay_float32_and_encoder_names_remap(tmp_path):
     assert back["talker.norm.weight"].dtype == torch.bfloat16
     from rho_tts_amd._native_model import to_native
     assert torch.equal(to_native(back, cfg)["enc.cbT0"].reshape(cb.shape[1], cb.shape[0]).t(), cb)
+
+
+def test_resolve_on_an_hf_config_json_keeps_the_kv_allocation(tmp_path):
+    """a real checkpoint's config.json says max_position_embeddings = 32768; that number may refine the segment
+    character limit (qwen.py:131-139) but must not size the KV caches (33 slots x 32768 rows of the 1.7B talker = 124 GB)."""
+    from rho_tts_amd._native_model import rt_config
+    d = tmp_path / "Qwen3-TTS-12Hz-1.7B-Base"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"talker_config": {"text_config": {"max_position_embeddings": 32768, "hidden_size": 2048}}}))
+    cfg = config.resolve(str(d))
+    base = config.qwen3_tts_1p7b()
+    assert cfg.hf_max_position_embeddings == 32768 and cfg.max_positions == base.max_positions == 4096
+    rc = rt_config(cfg, 32, cfg.max_positions, 325)
+    assert rc.max_positions == 4096 and rc.enc.max_ref_frames == 2048
+    t = cfg.talker
+    kv_bytes = 33 * cfg.max_positions * t.layers * 2 * t.kv_heads * t.head_dim * 2
+    assert kv_bytes < 16e9

@@ -265,3 +265,61 @@ def test_sampler_matches_oracle_draw_for_draw(ctx, V, sup_from):
         new_seen = seen.cpu().bool()
         for r in range(M):
             assert new_seen[r, got[r]]
+
+
+def _prefill_attention(ctx, q, slot, pos, k, v, prefix_slot, Lp, mode):
+    M, heads, d = q.shape
+    out = torch.empty(M, heads * d, dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.rt_debug_attention_prefill(ctx.handle, q.data_ptr(), M, heads, k.shape[1], d, slot.data_ptr(), pos.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                 k.shape[0], k.shape[2], prefix_slot, Lp, mode, out.data_ptr()), "rt_debug_attention_prefill")
+    return out
+
+
+@pytest.mark.parametrize("Lp,M", [(460, 43), (64, 9), (97, 1), (460, 416)])
+def test_prefill_attention_behind_a_shared_prefix_on_the_matrix_cores(ctx, Lp, M):
+    """The prompt rows' attention (texts' suffixes behind the voice prefix: 1.7B shape, 16 / 8 heads x 128) in its matrix-core form:
+    against float32, against the vector-unit kernel, an EXACT key census (q = 0 -> uniform softmax, V[p] = indicator of p mod d, so
+    output dim j is (number of visible positions congruent to j) / (pos + 1): a dropped or doubled key changes a count), and
+    batch invariance - every row alone gives the bits it gives among the others, whatever 8-row block it falls into."""
+    d, heads, kvh, slots, max_pos = 128, 16, 8, 5, 560
+    g = torch.Generator().manual_seed(33 + Lp + M)
+    k = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    v = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    q = torch.randn(M, heads, d, generator=g).cuda()
+    prefix_slot = slots - 1
+    slot = torch.randint(0, slots - 1, (M,), generator=g).to(torch.int32)
+    pos = (Lp + torch.randint(0, 60, (M,), generator=g)).to(torch.int32)
+    pos[0] = Lp                                                       # the first own row
+    if M > 2:
+        pos[1], pos[2] = Lp + 59, Lp + 31
+    slot_c, pos_c = slot.cuda(), pos.cuda()
+    out = _prefill_attention(ctx, q, slot_c, pos_c, k, v, prefix_slot, Lp, 1)
+    vec = _prefill_attention(ctx, q, slot_c, pos_c, k, v, prefix_slot, Lp, 0)
+    rep = heads // kvh
+    for r in range(min(M, 48)):
+        hi, sl = int(pos[r]), int(slot[r])
+        K = torch.cat([k[prefix_slot, :, :Lp], k[sl, :, Lp:hi + 1]], 1).float().repeat_interleave(rep, 0)
+        V = torch.cat([v[prefix_slot, :, :Lp], v[sl, :, Lp:hi + 1]], 1).float().repeat_interleave(rep, 0)
+        s = torch.einsum("hd,htd->ht", q[r], K) * d ** -0.5
+        ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V).reshape(-1)
+        assert float((out[r].float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), r
+    assert float((out.float() - vec.float()).abs().max()) < 3e-2
+    # batch invariance: rows alone, and a re-ordered batch
+    for r in (0, M // 2, M - 1):
+        alone = _prefill_attention(ctx, q[r:r + 1].contiguous(), slot_c[r:r + 1].contiguous(), pos_c[r:r + 1].contiguous(), k, v, prefix_slot, Lp, 1)
+        assert torch.equal(alone[0], out[r]), r
+    if M > 3:
+        perm = torch.randperm(M, generator=g)
+        shuffled = _prefill_attention(ctx, q[perm.cuda()].contiguous(), slot_c[perm.cuda()].contiguous(), pos_c[perm.cuda()].contiguous(), k, v, prefix_slot, Lp, 1)
+        assert torch.equal(shuffled, out[perm.cuda()])
+    # key census
+    ind = torch.zeros(max_pos, d)
+    ind[torch.arange(max_pos), torch.arange(max_pos) % d] = 1.0
+    v1 = ind.to(torch.bfloat16)[None, None].repeat(slots, kvh, 1, 1).cuda().contiguous()
+    cen = _prefill_attention(ctx, torch.zeros_like(q), slot_c, pos_c, k, v1, prefix_slot, Lp, 1).float().cpu().view(M, heads, d)
+    for r in range(min(M, 48)):
+        hi = int(pos[r])
+        want = torch.bincount(torch.arange(hi + 1) % d, minlength=d).float() / (hi + 1)
+        got = cen[r]
+        assert float((got - want.to(torch.bfloat16).float()[None]).abs().max()) <= 2 ** -9 * float(want.max()), r
