@@ -393,7 +393,8 @@ RT_API int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, 
 /* Prompt-prefill attention behind a shared prefix: q [M][heads][d] f32 (normed, roped), row r = sequence slot row_slot[r] at position
  * row_pos[r], whose K / V rows up to that position are already in the caches; positions < prefix_len are read from prefix_slot.
  * mode 0: the vector-unit kernel, 1: the matrix-core form the model uses for prompt rows (head_dim 128, 2 query heads per kv head,
- * prefix_len >= 64).  out [M][heads*d] bf16. */
+ * prefix_len >= 64), 2: the prefix slot's OWN prefill - rows must be positions 0 .. M - 1 of prefix_slot (M >= 64), causal, the keys in
+ * front of each 8-row block on the matrix cores.  out [M][heads*d] bf16. */
 RT_API int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
                                       const int32_t* d_row_slot, const int32_t* d_row_pos, const void* d_k, const void* d_v, int32_t slots,
                                       int32_t max_pos, int32_t prefix_slot, int32_t prefix_len, int32_t mode, void* d_out_bf16);

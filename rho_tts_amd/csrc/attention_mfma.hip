@@ -48,6 +48,8 @@ struct MfmaAttnArgs {
     int vt_stride;
     bf16_t* out; const float* qw; const float* kw; float eps; const float* cosT; const float* sinT;
     const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len;
+    int block_prefix = 0;             // prefill of the prefix slot ITSELF (consecutive rows of one slot, causal): the keys in front of a
+                                      // workgroup's first row play the part of the shared prefix, read from the tiles of the same slot
 };
 
 template <int ROWS, int NW, bool PREFILL>
@@ -75,7 +77,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
     for (int t = tid; t < 16 * QP; t += NW * 64) { (&sq_hi[0][0])[t] = 0; (&sq_lo[0][0])[t] = 0; }
     // the wave's first prefix block is requested BEFORE the prologue: it depends on nothing the prologue produces, so its L2
     // round trip runs under the prologue's own loads and reductions
-    const int Lp = g.prefix_len;
+    int Lp = g.prefix_len;
+    if (PREFILL && g.block_prefix) {                         // (uniform per workgroup; rows r0 .. r0 + ROWS - 1 sit at consecutive positions)
+        Lp = g.row_pos[r0 < g.M ? r0 : g.M - 1] + g.pos_add + frame;
+        if (Lp < 0) Lp = 0;
+    }
     const int gq = lane >> 4, n16 = lane & 15;               // MFMA lane split: k-octet / row-or-column
     const s8_t* ktp = reinterpret_cast<const s8_t*>(g.kt + (int64_t)kh * g.vt_stride) + lane;      // [block][tile 0..7][64 lanes] x 16 B
     const s8_t* vtp = reinterpret_cast<const s8_t*>(g.vt + (int64_t)kh * g.vt_stride) + lane;
@@ -408,6 +414,32 @@ int launch_attention_prefill_mfma(rt_ctx* ctx, const float* q, int M, int heads,
     g.prefix_slot = kv.prefix_slot; g.prefix_len = kv.prefix_len;
     hipLaunchKernelGGL((k_attn_prefix_mfma<8, 8, true>), dim3(kv_heads, (M + 7) / 8), dim3(8 * 64), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// The voice prefix's OWN prefill (rt_model_set_voice: n consecutive rows of the prefix slot, causal, no shared prefix yet): layer
+// by layer, right after k_qkv_post has written the layer's K / V rows, their fragment-tiled copies are made - the copies every later
+// prompt prefill reads anyway - and the attention of the layer runs on them: for a workgroup's 8 rows the keys in front of its
+// first row go through the matrix cores, the <= 8 keys from there on through the vector part.
+bool attention_block_prefix_ok(int M, int heads, int kv_heads, int head_dim, int window, const KvCache& kv) {
+    return g_prefill_attn_mfma && head_dim == D && kv.head_dim == D && heads == REP * kv_heads && window <= 0 && !kv.k_lo && kv.vt_prefix && kv.kt_prefix &&
+           kv.prefix_slot_alloc >= 0 && M >= 64 && (M + 31) / 32 * 4096 <= kv.vt_stride;
+}
+int launch_attention_block_prefix(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos,
+                                  KvCache& kv, int layer, bf16_t* out) {
+    hipLaunchKernelGGL(k_tile_prefix_kv, dim3(kv.kv_heads, 8), dim3(256), 0, ctx->stream, kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(),
+                       kv.kv_heads, kv.max_pos, kv.prefix_slot_alloc, M, kv.kt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride,
+                       kv.vt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride, kv.vt_stride);
+    RT_HIP(ctx, hipGetLastError());
+    MfmaAttnArgs g;
+    g.qkv = q; g.M = M; g.heads = heads; g.kv_heads = kv_heads; g.row_slot = row_slot; g.row_pos = row_pos; g.pos_add = 0;
+    g.kc = kv.k + layer * kv.layer_stride(); g.vc = kv.v + layer * kv.layer_stride(); g.max_pos = kv.max_pos;
+    g.kt = kv.kt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt = kv.vt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt_stride = kv.vt_stride;
+    g.out = out; g.qw = nullptr; g.kw = nullptr; g.eps = 0.f; g.cosT = nullptr; g.sinT = nullptr; g.frame_ptr = nullptr; g.out_tiled = 0;
+    g.prefix_slot = -1; g.prefix_len = 0; g.block_prefix = 1;
+    hipLaunchKernelGGL((k_attn_prefix_mfma<8, 8, true>), dim3(kv_heads, (M + 7) / 8), dim3(8 * 64), 0, ctx->stream, g);
+    RT_HIP(ctx, hipGetLastError());
+    if (layer + 1 == kv.layers) kv.tiles_len = M;            // every layer's tiles now hold the prefix
     return RT_OK;
 }
 

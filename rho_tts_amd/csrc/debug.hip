@@ -255,7 +255,21 @@ int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t
             return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_debug_attention_prefill: shape not served by the matrix-core form");
         }
     }
-    const int rc = launch_attention(ctx, d_q, M, heads, kv_heads, head_dim, d_row_slot, d_row_pos, 0, 0, kv, 0, (bf16_t*)d_out_bf16);
+    int rc;
+    if (mode == 2) {        // the prefix slot's own prefill: rows = positions 0 .. M - 1 of prefix_slot, causal (tiles made by the call itself)
+        kv.prefix_slot = -1; kv.prefix_len = 0;
+        kv.vt_stride = std::max(kv.vt_stride, (M + 31) / 32 * 4096);
+        if (vt) { (void)hipFree(vt); vt = nullptr; }
+        hipError_t me = hipMalloc((void**)&vt, (size_t)2 * kv_heads * kv.vt_stride * 2);
+        if (me != hipSuccess) { g_prefill_attn_mfma = saved; return rt_fail(ctx, rt_hip_status(me), "rt_debug_attention_prefill: out of memory"); }
+        kv.kt_prefix = vt;
+        kv.vt_prefix = vt + (size_t)kv_heads * kv.vt_stride;
+        rc = attention_block_prefix_ok(M, heads, kv_heads, head_dim, 0, kv)
+                 ? launch_attention_block_prefix(ctx, d_q, M, heads, kv_heads, d_row_slot, d_row_pos, kv, 0, (bf16_t*)d_out_bf16)
+                 : rt_fail(ctx, RT_ERR_UNSUPPORTED, "rt_debug_attention_prefill: shape not served by the block-prefix form");
+    } else {
+        rc = launch_attention(ctx, d_q, M, heads, kv_heads, head_dim, d_row_slot, d_row_pos, 0, 0, kv, 0, (bf16_t*)d_out_bf16);
+    }
     const hipError_t se = hipStreamSynchronize(ctx->stream);
     g_prefill_attn_mfma = saved;
     if (vt) (void)hipFree(vt);

@@ -214,6 +214,10 @@ int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len);
 // prompt rows (q prepared by launch_qkv_post, K / V appended) behind a shared prefix on the matrix cores: bf16 out [M][heads * d]
 extern int g_prefill_attn_mfma;
 bool attention_prefill_mfma_ok(int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
+// the prefix slot's own prefill: tiles layer `layer` of the prefix, then causal attention of its M consecutive rows on those tiles
+bool attention_block_prefix_ok(int M, int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
+int launch_attention_block_prefix(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos,
+                                  KvCache& kv, int layer, bf16_t* out);
 int launch_attention_prefill_mfma(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
                                   const KvCache& kv, int layer, bf16_t* out);
 

@@ -416,8 +416,10 @@ int alloc_stack_ws(rt_model* m, const rt_stack_dims& d, int M, StackWs* w, bool 
 }
 
 // x [M][H] f32 in/out (residual stream); on return out_bf16/out_f32 hold the final-norm output.
+// prefix_rows: the rows are the voice prefix itself (consecutive positions of the prefix slot): its attention runs on the
+// matrix cores over the layer's freshly tiled K / V (launch_attention_block_prefix) where that form applies
 int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
-                  bf16_t* out_bf16, float* out_f32, const int32_t* frame_ptr = nullptr) {
+                  bf16_t* out_bf16, float* out_f32, const int32_t* frame_ptr = nullptr, bool prefix_rows = false) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden;
@@ -453,7 +455,10 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
         RT_TRY(gemm_rows(m, w.xn, M, L.wqkv, w.slabs, &ns));
         RT_TRY(launch_qkv_post(ctx, w.slabs, ns, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
                                pos_add, w.q, S.kv, i, frame_ptr));
-        RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr));
+        if (prefix_rows && pos_add == 0 && !frame_ptr && attention_block_prefix_ok(M, d.heads, d.kv_heads, d.head_dim, S.window, S.kv))
+            RT_TRY(launch_attention_block_prefix(ctx, w.q, M, d.heads, d.kv_heads, row_slot, row_pos, S.kv, i, w.ao));
+        else
+            RT_TRY(launch_attention(ctx, w.q, M, d.heads, d.kv_heads, d.head_dim, row_slot, row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr));
         RT_TRY(gemm_rows(m, w.ao, M, L.wo, w.slabs, &ns));
         RT_TRY(launch_add_rmsnorm(ctx, x, M, H, w.slabs, ns, nullptr, L.ls1, L.ln2, d.rms_eps, w.xn, nullptr));
         RT_TRY(gemm_rows(m, w.xn, M, L.wgu, w.slabs, &ns));
@@ -881,12 +886,12 @@ static int set_voice_impl(rt_model* m, int32_t n_rows, const int32_t* h_text_ids
     RT_TRY(alloc_stack_ws(m, c.talker, n_rows, &w));
     bf16_t* hn = nullptr;
     RT_TRY(pool_arr(m, (size_t)n_rows * H, &hn));
-    RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr));
-    // fragment-tiled copies of the prefix K / V for the matrix-core attention of the prompt prefills (and of the decode step when
-    // that form is switched on): once per voice
-    m->prefix_tiles_valid = false;
     m->talker.kv.tiles_len = -1;
-    if (c.talker.head_dim == 128 && m->talker.kv.kt_prefix) {
+    RT_TRY(stack_forward(m, m->talker, w, x, n_rows, d_slot, d_pos, 0, hn, nullptr, nullptr, true));
+    // fragment-tiled copies of the prefix K / V for the matrix-core attention of the prompt prefills (and of the decode step when
+    // that form is switched on): once per voice - made layer by layer inside the prefill above where its attention used them
+    m->prefix_tiles_valid = m->talker.kv.tiles_len == n_rows;
+    if (!m->prefix_tiles_valid && c.talker.head_dim == 128 && m->talker.kv.kt_prefix) {
         RT_TRY(launch_transpose_prefix_v(ctx, m->talker.kv, n_rows));
         m->prefix_tiles_valid = true;
     }

@@ -323,3 +323,32 @@ def test_prefill_attention_behind_a_shared_prefix_on_the_matrix_cores(ctx, Lp, M
         want = torch.bincount(torch.arange(hi + 1) % d, minlength=d).float() / (hi + 1)
         got = cen[r]
         assert float((got - want.to(torch.bfloat16).float()[None]).abs().max()) <= 2 ** -9 * float(want.max()), r
+
+
+@pytest.mark.parametrize("M", [460, 64, 131])
+def test_prefix_self_prefill_attention_on_the_matrix_cores(ctx, M):
+    """rt_model_set_voice's own attention (the voice prefix attending to itself: M consecutive rows of one slot, causal): the keys in
+    front of each 8-row block on the matrix cores, the block's own <= 8 keys on the vector unit - against float32 and with the exact
+    key census (row p sees exactly positions 0 .. p)."""
+    d, heads, kvh, slots, max_pos = 128, 16, 8, 2, 512
+    g = torch.Generator().manual_seed(90 + M)
+    k = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    v = (torch.randn(slots, kvh, max_pos, d, generator=g)).to(torch.bfloat16).cuda()
+    q = torch.randn(M, heads, d, generator=g).cuda()
+    slot = torch.ones(M, dtype=torch.int32).cuda()
+    pos = torch.arange(M, dtype=torch.int32).cuda()
+    out = _prefill_attention(ctx, q, slot, pos, k, v, 1, M, 2)
+    rep = heads // kvh
+    for r in list(range(0, M, 37)) + [7, 8, 31, 32, M - 1]:
+        K = k[1, :, :r + 1].float().repeat_interleave(rep, 0)
+        V = v[1, :, :r + 1].float().repeat_interleave(rep, 0)
+        s = torch.einsum("hd,htd->ht", q[r], K) * d ** -0.5
+        ref = torch.einsum("ht,htd->hd", torch.softmax(s, -1), V).reshape(-1)
+        assert float((out[r].float() - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), r
+    ind = torch.zeros(max_pos, d)
+    ind[torch.arange(max_pos), torch.arange(max_pos) % d] = 1.0
+    v1 = ind.to(torch.bfloat16)[None, None].repeat(slots, kvh, 1, 1).cuda().contiguous()
+    cen = _prefill_attention(ctx, torch.zeros_like(q), slot, pos, k, v1, 1, M, 2).float().cpu().view(M, heads, d)
+    for r in range(M):
+        want = torch.bincount(torch.arange(r + 1) % d, minlength=d).float() / (r + 1)
+        assert float((cen[r] - want.to(torch.bfloat16).float()[None]).abs().max()) <= 2 ** -9 * float(want.max()), r
