@@ -212,6 +212,7 @@ def main():
     # ---- roofline of the dominant kernel (weight-streaming skinny GEMM), HIP events on the library's stream
     roof = None
     extra = {}
+    extra_families = None
     if not args.no_roofline:
         eng.model.profile(True)
         step()
@@ -262,7 +263,7 @@ def main():
         ctx_len = eng.model.prefix_len() + args.words + 3 + frames // 2
         kv = B * ctx_len * t_.layers * 2 * t_.kv_heads * t_.head_dim * 2
         extra = {"bytes_per_frame": int(w_talker + w_pred + kv), "frames_per_item": frames, "prefix_rows": eng.model.prefix_len()}
-        if roof is not None and locals().get("extra_families"):
+        if roof is not None and extra_families:
             extra["kernel_families"] = extra_families
     if corpus is not None:
         extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(actual)), "length_error": args.length_error,

@@ -51,13 +51,16 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 // clamped so every request is a valid address).  Branch-free matters: the row-scale partials are requested just before the
 // chunks, and only when the number of younger loads is a compile-time constant can the compiler wait for them with a
 // counted `s_waitcnt vmcnt(N)` instead of draining the weight chunks too.  NPRE = 0 keeps the fully guarded form (any K).
+// MT = 1 (M <= 16: one of several decode LANES, rt_debug_tune 40n) is held to 128 VGPRs so that two workgroups - of two
+// different lanes' launches - share a CU: two dependent chains can then really run side by side (with one workgroup per CU a
+// second stream's kernel only queues behind the first).
 template <int EPI, int MT, int NPRE>
-__global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_gemm_col(ColArgs g) {
+__global__ __launch_bounds__(512, ((EPI == COL_SILU && MT == 2) || MT == 1) ? 4 : 2) void k_gemm_col(ColArgs g) {
     __shared__ float red[WAVES][MT][4][64];  // 16 KiB per 32 rows: one 16x16 accumulator tile per sub-block and wave
     __shared__ float sh_inv[16 * MT];        // RMSNorm row scales
     constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int C = (NB == 2) ? 2 : (MT == 4 ? 4 : 8);     // k-tiles (32 deep) per super-chunk
-    constexpr int PASSES = MT / 2;           // epilogue / row-scale passes of 32 rows
+    constexpr int C = (NB == 2) ? 2 : ((MT == 4 || MT == 1) ? 4 : 8);     // k-tiles (32 deep) per super-chunk
+    constexpr int PASSES = (MT + 1) / 2;     // epilogue / row-scale passes of 32 rows (MT = 1: half of one)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, qd = lane >> 4;
     const int sp_shift = g.split == 4 ? 2 : (g.split == 2 ? 1 : 0);
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (r == 0) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
+            if (r == 0 && row_i < 16 * MT) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
         }
     }
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[1] = wall_clock64();
@@ -209,8 +212,11 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             float s = 0.f;
+            const int smt = 2 * ps + (tid >> 8);               // (MT = 1: the upper half of the workgroup has no sub-block)
+            if (smt < MT) {
 #pragma unroll
-            for (int ww = 0; ww < WAVES; ++ww) s += red[ww][2 * ps + (tid >> 8)][e_i][e_l];
+                for (int ww = 0; ww < WAVES; ++ww) s += red[ww][smt < MT ? smt : 0][e_i][e_l];
+            }
             val[b][ps] = s;
         }
     }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512, (EPI == COL_SILU && MT == 2) ? 4 : 2) void k_g
     for (int ps = 0; ps < PASSES; ++ps) {
         const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
         const bool ok = e_row < g.M && n_ok;
-        const float inv = g.post_scale ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
+        const float inv = (g.post_scale && e_row < 16 * MT) ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
         float v = val[0][ps] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
@@ -259,7 +265,7 @@ void launch_one(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEven
 template <int EPI, int MT>
 void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     // every wave needs at least one k-tile for the clamped (branch-free) requests to be valid addresses
-    constexpr int C = (EPI == COL_SILU) ? 2 : (MT == 4 ? 4 : 8);
+    constexpr int C = (EPI == COL_SILU) ? 2 : ((MT == 4 || MT == 1) ? 4 : 8);
     const int kchunk = (g.KT + WAVES - 1) / WAVES;
     const bool all_waves_busy = g.KT >= WAVES && (WAVES - 1) * kchunk < g.KT;
     const int n_sc = (kchunk + C - 1) / C;
@@ -269,11 +275,11 @@ void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 }
 
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
-    const bool wide = g.M > 32;
+    const bool wide = g.M > 32, narrow = g.M <= 16 && g_col_rows16;
     switch (g.epi) {
-        case COL_STORE: wide ? launch_npre<COL_STORE, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
-        case COL_RESID: wide ? launch_npre<COL_RESID, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
-        case COL_SILU: wide ? launch_npre<COL_SILU, 4>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
+        case COL_STORE: wide ? launch_npre<COL_STORE, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_STORE, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
+        case COL_RESID: wide ? launch_npre<COL_RESID, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_RESID, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
+        case COL_SILU: wide ? launch_npre<COL_SILU, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_SILU, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
         default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -285,6 +291,7 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 // gate/up GEMM (N = 2 * inter): a workgroup owns a gate tile and its up tile, N/32 workgroups.  Halving the tiles to even out
 // the 1.5 rounds of the 1.7B talker (384 workgroups on 256 CUs) was measured slower (21.5 vs 17.4 us: every workgroup
 // re-reads the whole A operand), so the split is only taken when forced through rt_debug_tune(502/504).
+int g_col_rows16 = 0;            // 1: launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU: decode lanes, rt_debug_tune 2301)
 int g_col_split4 = 0;            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
 int col_split_silu(int N, int n_cu) {
     (void)N; (void)n_cu;

@@ -99,7 +99,8 @@ extern int g_prefill_fill;         // prefill GEMMs split K until the grid holds
 extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
 extern int g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
 extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
-extern int g_col_split4;          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
+extern int g_col_split4;
+extern int g_col_rows16;         // 1: <= 16-row decode GEMM launches on the two-workgroups-per-CU instantiation (decode lanes)          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
 int col_split_for(int N, int n_cu);
 int col_split_silu(int N, int n_cu);
 extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)

@@ -123,7 +123,7 @@ def gather_waveforms(wavs: Sequence[torch.Tensor], dist, dst: int = 0, device=No
     n_local = torch.tensor([lens.numel()], dtype=torch.int64, device=device)
     counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts, n_local)
-    max_items = int(max(int(c) for c in counts))
+    max_items = max(1, int(max(int(c) for c in counts)))       # (a collective on empty tensors is not something every backend accepts)
     lens_pad = torch.full((max_items,), -1, dtype=torch.int64, device=device)
     lens_pad[: lens.numel()] = lens
     all_lens = [torch.empty_like(lens_pad) for _ in range(world)]

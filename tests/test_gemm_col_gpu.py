@@ -112,6 +112,18 @@ def test_gemm_col_integer_exact(ctx, N, K, epi, norm, name, M):
                 assert bool((got[(g == 0) | (u == 0)] == 0).all())
 
 
+@pytest.mark.parametrize("M", [1, 8, 16])
+def test_gemm_col_sixteen_row_instantiation_is_exact(ctx, M):
+    """rt_debug_tune(2301): launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU, what decode lanes
+    would run side by side - measured: no gain, DESIGN.md section 6, kept as a knob).  Same integer-exact checks on every shape."""
+    ctx.lib.rt_debug_tune(2301, 0)
+    try:
+        for N, K, epi, norm, name in SHAPES:
+            test_gemm_col_integer_exact(ctx, N, K, epi, norm, name, M)
+    finally:
+        ctx.lib.rt_debug_tune(2300, 0)
+
+
 @pytest.mark.parametrize("N,K,epi,norm,name", SHAPES, ids=[s[4] for s in SHAPES])
 def test_gemm_col_random_operands(ctx, N, K, epi, norm, name):
     """Random bf16 operands, real RMSNorm partials: tolerance 2e-3 of the output scale (f32 accumulation in another order)."""
