@@ -226,17 +226,16 @@ def main():
             # HBM-side bytes per launch: counters cannot be read from inside this process, so `traffic` is the FETCH_SIZE of the
             # SAME step (same model, batch, prompt and launch sequence) collected by `rocprofv3 --pmc FETCH_SIZE -- python3 bench.py
             # --steps 1 --warmup 0 --tune 200,1301` and reduced by tools/pmc_step_split.py (x 1024 x 2: KiB, gfx950 correction)
-            # The counters belong to ONE build of the library: the profile records the SHA-256 of librho_tts_amd.so it was taken with, and
-            # a different library (any kernel change) reports traffic = null rather than stale bytes.
+            # The counters belong to ONE build of the library: the profile records the SHA-256 of the native sources it was taken with
+            # (rho_tts_amd._build.source_hash), and any other build (any kernel change) reports traffic = null rather than stale bytes.
             default_workload = args.model == "1.7b" and B == 32 and args.words == 10 and args.ref_seconds == 30.0 and corpus is None
             try:
-                import hashlib
-                with open(os.path.join(ROOT, "rho_tts_amd", "librho_tts_amd.so"), "rb") as f:
-                    lib_sha = hashlib.sha256(f.read()).hexdigest()
+                from rho_tts_amd._build import source_hash
+                lib_sha = source_hash()
                 with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
                     pmc = json.load(f)
-                roof["lib_sha256"] = lib_sha[:16]
-                if default_workload and pmc["k_gemm_col_dispatches"] == int(n_l) and pmc.get("lib_sha256", "")[:16] == lib_sha[:16]:
+                roof["build_sha256"] = lib_sha[:16]
+                if default_workload and pmc["k_gemm_col_dispatches"] == int(n_l) and pmc.get("build_sha256", "")[:16] == lib_sha[:16]:
                     roof["traffic"] = float(pmc["all"]["fetched_bytes_per_dispatch"])
                     roof["traffic_source"] = ("FETCH_SIZE x 1024 x 2 per k_gemm_col dispatch, counter pass over bench.py itself "
                                               "(profiles/" + PMC_PROFILE + ": fetched / algorithmic = %.3f; talker layers %.3f, "
@@ -244,11 +243,11 @@ def main():
                                               % (pmc["all"]["fetched_over_algorithmic"], pmc["classes"]["talker layers"]["fetched_over_algorithmic"],
                                                  pmc["classes"]["predictor layers"]["fetched_over_algorithmic"]))
                 elif default_workload:
-                    roof["traffic_source"] = ("null: profiles/" + PMC_PROFILE + " was collected with another build of librho_tts_amd.so "
-                                              "(sha256 %s..., %d k_gemm_col dispatches) - re-run tools/pmc_step_split.py" % (pmc.get("lib_sha256", "?")[:16], pmc["k_gemm_col_dispatches"]))
+                    roof["traffic_source"] = ("null: profiles/" + PMC_PROFILE + " was collected with another build of the native sources "
+                                              "(sha256 %s..., %d k_gemm_col dispatches) - re-run tools/collect_profiles.sh" % (pmc.get("build_sha256", "?")[:16], pmc["k_gemm_col_dispatches"]))
                 # HBM GB/s and MFMA-busy per kernel family against the chip's peaks (north_star): from the committed rocprofv3 passes of
                 # this same build (kernel trace for time, FETCH_SIZE / SQ_VALU_MFMA_BUSY_CYCLES passes for bytes and matrix-core use)
-                if pmc.get("lib_sha256", "")[:16] == lib_sha[:16] and "families" in pmc:
+                if pmc.get("build_sha256", "")[:16] == lib_sha[:16] and "families" in pmc:
                     extra_families = pmc["families"]
                 else:
                     extra_families = None

@@ -42,6 +42,22 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def source_hash() -> str:
+    """SHA-256 over the native sources (csrc/*.hip, csrc/*.h, include/rho_tts_amd.h, the compiler flags): what identifies a BUILD of
+    the library independently of where and when hipcc ran (the .so itself is rebuilt by every fresh checkout and need not come out
+    byte-identical).  profiles/*.json record it; bench.py reports counter figures only for the build they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "rho_tts_amd.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(CXXFLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(PER_FILE.items())]).encode())
+    return h.hexdigest()
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
