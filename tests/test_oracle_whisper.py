@@ -93,3 +93,25 @@ def test_to_native_layouts():
     got = torch.cat([prev, rows], dim=1) @ c2.float().t()
     assert float((got - want).abs().max()) < 1e-4
     assert len(nat) == len(set(nat)) and all(t.dtype in (torch.bfloat16, torch.float32) for t in nat.values())
+
+
+def test_checkpoint_directory_round_trip(tmp_path):
+    """The real-checkpoint path of the speech-to-text model, exercised offline: transformers' own `save_pretrained` layout
+    (model.safetensors with its tensor names, config.json) is read back by `stt.load_checkpoint` / `SttConfig.from_hf`."""
+    import json
+    cfg = S.tiny_test_config()
+    state = S.synthetic_state(cfg, 789)
+    model = OW.build(cfg, state)
+    d = str(tmp_path / "whisper-test")
+    model.save_pretrained(d, safe_serialization=True)
+    js = json.load(open(os.path.join(d, "config.json")))
+    c2 = S.SttConfig.from_hf(js)
+    assert (c2.d_model, c2.heads, c2.ffn, c2.enc_layers, c2.dec_layers, c2.n_mels, c2.n_ctx, c2.n_text_ctx, c2.vocab) == \
+           (cfg.d_model, cfg.heads, cfg.ffn, cfg.enc_layers, cfg.dec_layers, cfg.n_mels, cfg.n_ctx, cfg.n_text_ctx, cfg.vocab)
+    assert c2.eos_id == cfg.eos_id
+    back = S.load_checkpoint(cfg, d)
+    assert set(back) == set(state)
+    for k in state:
+        assert torch.equal(back[k].float(), state[k].float()), k
+    with pytest.raises(ValueError, match="checkpoint shape|missing"):
+        S.load_checkpoint(S.SttConfig(), d)                        # another architecture: shapes / tensors do not fit

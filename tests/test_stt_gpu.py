@@ -112,3 +112,30 @@ def test_validation_runs_on_the_device_without_a_file(monkeypatch):
         tr.close()
     finally:
         t.close()
+
+
+def test_transcriber_from_a_checkpoint_directory(ctx, tmp_path):
+    """`WhisperTranscriber(model_dir=...)`: transformers' save_pretrained layout + a tokenizer.json -> the same ids as the seeded
+    state it was written from, decoded to text through the tokenizer (the path a real whisper-tiny directory takes)."""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    cfg = S.tiny_test_config()
+    state = S.synthetic_state(cfg, 789)
+    d = str(tmp_path / "whisper-test")
+    OW.build(cfg, state).save_pretrained(d, safe_serialization=True)
+    tok = Tokenizer(WordLevel({f"w{i}": i for i in range(cfg.vocab)}, unk_token="w0"))
+    tok.pre_tokenizer = Whitespace()
+    tok.save(d + "/tokenizer.json")
+    x = clip(1.2, 24000, 8)
+    tr = S.WhisperTranscriber(ctx, model_dir=d)
+    ref = S.WhisperTranscriber(ctx, synthetic=True, cfg=cfg)
+    try:
+        ids = tr.ids(torch.from_numpy(x).cuda(), 24000)
+        assert ids == ref.ids(x, 24000) and len(ids) > 0
+        text = tr(torch.from_numpy(x).cuda(), 24000)
+        assert text.split() == [f"w{i}" for i in ids]
+        assert ref(x, 24000) == " ".join(f"<{i}>" for i in ids)
+    finally:
+        tr.close()
+        ref.close()
