@@ -47,6 +47,23 @@ class GenerationParams:
         return RtSampling(int(ds), self.predictor_temperature, self.predictor_top_k, self.predictor_top_p, 1.0)
 
 
+def pick_rows(plan: Sequence[int], max_batch: int) -> int:
+    """Decode rows for a work list with estimated lengths ``plan`` on an engine of ``max_batch`` rows.  A frame on 33..64 rows
+    costs up to ~1.4x a frame on 32 (measured), and a list-scheduled queue on R rows takes about
+    max(longest, sum / R) frames: 32 busy rows with a queue beat 64 half-idle ones only when the lengths are ragged enough - so
+    the narrower schedule is taken only when this model puts it clearly (10 %) ahead; n <= max_batch texts of similar length
+    stay one static batch."""
+    n = len(plan)
+    full = min(n, max_batch)
+    if full <= 32 or not plan:
+        return full
+
+    def cost(rows: int) -> float:
+        frames = max(float(max(plan)), float(sum(plan)) / rows)
+        return frames * (1.0 + 0.4 * max(0, rows - 32) / 32.0)
+    return 32 if cost(32) < 0.9 * cost(full) else full
+
+
 SYNTHETIC_ENV = "RHO_TTS_AMD_SYNTHETIC"
 
 
@@ -240,19 +257,7 @@ class Engine:
         return bucket_batches(frames, self.max_batch)
 
     def pick_rows(self, plan: Sequence[int]) -> int:
-        """Decode rows for a work list with estimated lengths ``plan``.  A frame on 33..64 rows costs up to ~1.4x a frame on 32
-        (measured), and a list-scheduled queue on R rows takes about max(longest, sum / R) frames: 32 busy
-        rows with a queue beat 64 half-idle ones only when the lengths are ragged enough - so the narrower schedule is taken
-        only when this model puts it clearly (10 %) ahead; n <= max_batch texts of similar length stay one static batch."""
-        n = len(plan)
-        full = min(n, self.max_batch)
-        if full <= 32 or not plan:
-            return full
-
-        def cost(rows: int) -> float:
-            frames = max(float(max(plan)), float(sum(plan)) / rows)
-            return frames * (1.0 + 0.4 * max(0, rows - 32) / 32.0)
-        return 32 if cost(32) < 0.9 * cost(full) else full
+        return pick_rows(plan, self.max_batch)
 
     def synthesize(self, texts: Sequence[str], seed: int = 789, item_ids: Optional[Sequence[int]] = None, cancel_flag=None,
                    max_frames: Optional[Sequence[int]] = None, stats: Optional[dict] = None,

@@ -343,3 +343,16 @@ def test_provider_data_parallel_world_size_2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def test_pick_rows_cost_model():
+    """the short-queue rule must not assume max_batch == 64 - n <= max_batch texts of similar length stay one static
+    batch; 32 busy rows are only taken when the cost model puts them clearly ahead (ragged lengths on a 64-row engine)."""
+    from rho_tts_amd.engine import pick_rows
+    assert pick_rows([44] * 20, 32) == 20 and pick_rows([44] * 32, 64) == 32 and pick_rows([], 64) == 0
+    assert pick_rows([44] * 64, 64) == 64                              # equal lengths: one 64-row batch (bench.py --batch 64)
+    assert pick_rows([44] * 40, 48) == 40                              # the advisor's example: no forced 32 rows + queue
+    ragged = [26 + (37 * i) % 80 for i in range(64)]                   # 26..105 frames, evenly spread
+    assert pick_rows(ragged, 64) == 32                                 # measured: 423 against 396 audio-s/s (DESIGN.md section 7)
+    assert pick_rows(ragged * 8, 64) == 64                             # a long queue keeps 64 rows busy
+    assert pick_rows(ragged, 32) == 32 and pick_rows(ragged[:33], 64) in (32, 33)
