@@ -50,7 +50,9 @@ class SttConfig:
     max_new_tokens: int = 224
 
     @staticmethod
-    def from_hf(js: dict) -> "SttConfig":
+    def from_hf(js: dict, generation: Optional[dict] = None, preprocessor: Optional[dict] = None) -> "SttConfig":
+        """From a checkpoint directory's ``config.json`` (+ ``generation_config.json`` for the forced prefix and the suppressed
+        ids, + ``preprocessor_config.json`` for the feature extractor), as transformers' ``save_pretrained`` writes them."""
         c = SttConfig()
         c.d_model = js.get("d_model", c.d_model)
         c.heads = js.get("encoder_attention_heads", c.heads)
@@ -58,13 +60,45 @@ class SttConfig:
         c.enc_layers, c.dec_layers = js.get("encoder_layers", c.enc_layers), js.get("decoder_layers", c.dec_layers)
         c.n_mels, c.n_ctx = js.get("num_mel_bins", c.n_mels), js.get("max_source_positions", c.n_ctx)
         c.n_text_ctx, c.vocab = js.get("max_target_positions", c.n_text_ctx), js.get("vocab_size", c.vocab)
-        c.eos_id = js.get("eos_token_id", c.eos_id)
-        if js.get("begin_suppress_tokens"):
-            c.begin_suppress = tuple(js["begin_suppress_tokens"])[:4]
-        if js.get("forced_decoder_ids"):
-            c.prefix = (js.get("decoder_start_token_id", c.prefix[0]),) + tuple(t for _, t in js["forced_decoder_ids"])
-        c.suppress_from = min(c.eos_id, c.suppress_from) if c.vocab > c.suppress_from else 0
+        pre = preprocessor or {}
+        c.n_fft, c.hop = int(pre.get("n_fft", c.n_fft)), int(pre.get("hop_length", c.hop))
+        c.sample_rate, c.n_mels = int(pre.get("sampling_rate", c.sample_rate)), int(pre.get("feature_size", c.n_mels))
+        # the encoder's two convolutions halve the frames: one chunk is 2 n_ctx hops (30 s for n_ctx 1500)
+        c.chunk_seconds = int(pre.get("chunk_length", max(1, round(2 * c.n_ctx * c.hop / c.sample_rate))))
+        gen = dict(js)
+        gen.update({k: v for k, v in (generation or {}).items() if v is not None})
+        eos = gen.get("eos_token_id", c.eos_id)
+        c.eos_id = int(eos[0] if isinstance(eos, (list, tuple)) else eos)
+        start = int(gen.get("decoder_start_token_id", c.prefix[0]))
+        if gen.get("forced_decoder_ids"):
+            c.prefix = (start,) + tuple(int(t) for _, t in sorted(gen["forced_decoder_ids"]) if t is not None)
+        elif gen.get("lang_to_id") and gen.get("task_to_id"):          # newer generation configs name the ids instead
+            c.prefix = (start, int(gen["lang_to_id"].get("<|en|>", start + 1)), int(gen["task_to_id"].get("transcribe", start + 2)))
+            if gen.get("no_timestamps_token_id") is not None:
+                c.prefix += (int(gen["no_timestamps_token_id"]),)
+        elif start != c.prefix[0]:
+            c.prefix = (start,)
+        if gen.get("begin_suppress_tokens"):
+            c.begin_suppress = tuple(int(t) for t in gen["begin_suppress_tokens"] if 0 <= int(t) < c.vocab)[:4]
+        # Whisper's vocabularies put every special id (language, task, timestamps) behind end-of-sequence
+        c.suppress_from = c.eos_id if 0 < c.eos_id < c.vocab else 0
+        if gen.get("max_new_tokens"):
+            c.max_new_tokens = int(gen["max_new_tokens"])
+        c.max_new_tokens = max(1, min(c.max_new_tokens, c.n_text_ctx - len(c.prefix)))
         return c
+
+    @staticmethod
+    def from_dir(model_dir: str) -> "SttConfig":
+        def read(name):
+            path = os.path.join(model_dir, name)
+            if not os.path.exists(path):
+                return None
+            with open(path) as f:
+                return json.load(f)
+        js = read("config.json")
+        if js is None:
+            raise ValueError(f"no config.json in {model_dir!r}")
+        return SttConfig.from_hf(js, read("generation_config.json"), read("preprocessor_config.json"))
 
 
 def tiny_test_config() -> SttConfig:
@@ -343,11 +377,8 @@ class WhisperTranscriber:
         self.tokenizer = None
         dev = f"cuda:{ctx.device_ordinal}"
         if model_dir and os.path.isdir(model_dir) and any(f.endswith(".safetensors") for f in os.listdir(model_dir)):
-            cfg_path = os.path.join(model_dir, "config.json")
-            if cfg is None and os.path.exists(cfg_path):
-                with open(cfg_path) as f:
-                    cfg = SttConfig.from_hf(json.load(f))
-            cfg = cfg or SttConfig()
+            if cfg is None:
+                cfg = SttConfig.from_dir(model_dir) if os.path.exists(os.path.join(model_dir, "config.json")) else SttConfig()
             state = load_checkpoint(cfg, model_dir, device=dev)
             tok_path = os.path.join(model_dir, "tokenizer.json")
             if os.path.exists(tok_path):

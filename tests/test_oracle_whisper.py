@@ -95,6 +95,17 @@ def test_to_native_layouts():
     assert len(nat) == len(set(nat)) and all(t.dtype in (torch.bfloat16, torch.float32) for t in nat.values())
 
 
+def write_sidecar_configs(d, cfg):
+    """What a Whisper checkpoint directory carries beside config.json (values of ``cfg``)."""
+    import json
+    with open(os.path.join(d, "generation_config.json"), "w") as f:
+        json.dump({"eos_token_id": cfg.eos_id, "decoder_start_token_id": int(cfg.prefix[0]), "max_new_tokens": cfg.max_new_tokens,
+                   "forced_decoder_ids": [[i + 1, int(t)] for i, t in enumerate(cfg.prefix[1:])], "begin_suppress_tokens": list(cfg.begin_suppress)}, f)
+    with open(os.path.join(d, "preprocessor_config.json"), "w") as f:
+        json.dump({"chunk_length": cfg.chunk_seconds, "feature_size": cfg.n_mels, "hop_length": cfg.hop, "n_fft": cfg.n_fft,
+                   "sampling_rate": cfg.sample_rate}, f)
+
+
 def test_checkpoint_directory_round_trip(tmp_path):
     """The real-checkpoint path of the speech-to-text model, exercised offline: transformers' own `save_pretrained` layout
     (model.safetensors with its tensor names, config.json) is read back by `stt.load_checkpoint` / `SttConfig.from_hf`."""
@@ -108,7 +119,17 @@ def test_checkpoint_directory_round_trip(tmp_path):
     c2 = S.SttConfig.from_hf(js)
     assert (c2.d_model, c2.heads, c2.ffn, c2.enc_layers, c2.dec_layers, c2.n_mels, c2.n_ctx, c2.n_text_ctx, c2.vocab) == \
            (cfg.d_model, cfg.heads, cfg.ffn, cfg.enc_layers, cfg.dec_layers, cfg.n_mels, cfg.n_ctx, cfg.n_text_ctx, cfg.vocab)
-    assert c2.eos_id == cfg.eos_id
+    assert c2.eos_id == cfg.eos_id and c2.chunk_seconds == cfg.chunk_seconds and c2.prefix[0] == cfg.prefix[0]
+    assert all(t < cfg.vocab for t in c2.begin_suppress)
+    write_sidecar_configs(d, cfg)                                  # generation_config.json + preprocessor_config.json
+    assert S.SttConfig.from_dir(d) == cfg
+    whisper_tiny = {"d_model": 384, "encoder_attention_heads": 6, "encoder_ffn_dim": 1536, "encoder_layers": 4, "decoder_layers": 4,
+                    "num_mel_bins": 80, "max_source_positions": 1500, "max_target_positions": 448, "vocab_size": 51865, "eos_token_id": 50257,
+                    "decoder_start_token_id": 50258, "forced_decoder_ids": [[1, 50259], [2, 50359], [3, 50363]], "begin_suppress_tokens": [220, 50257]}
+    assert S.SttConfig.from_hf(whisper_tiny) == S.SttConfig()      # the published whisper-tiny config.json keys -> the defaults
+    named = dict(whisper_tiny, forced_decoder_ids=None)
+    gen = {"lang_to_id": {"<|en|>": 50259, "<|de|>": 50261}, "task_to_id": {"transcribe": 50359, "translate": 50358}, "no_timestamps_token_id": 50363}
+    assert S.SttConfig.from_hf(named, gen).prefix == S.SttConfig().prefix
     back = S.load_checkpoint(cfg, d)
     assert set(back) == set(state)
     for k in state:

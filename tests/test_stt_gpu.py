@@ -127,8 +127,11 @@ def test_transcriber_from_a_checkpoint_directory(ctx, tmp_path):
     tok = Tokenizer(WordLevel({f"w{i}": i for i in range(cfg.vocab)}, unk_token="w0"))
     tok.pre_tokenizer = Whitespace()
     tok.save(d + "/tokenizer.json")
+    from tests.test_oracle_whisper import write_sidecar_configs
+    write_sidecar_configs(d, cfg)
     x = clip(1.2, 24000, 8)
     tr = S.WhisperTranscriber(ctx, model_dir=d)
+    assert tr.cfg == cfg
     ref = S.WhisperTranscriber(ctx, synthetic=True, cfg=cfg)
     try:
         ids = tr.ids(torch.from_numpy(x).cuda(), 24000)
