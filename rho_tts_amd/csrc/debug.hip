@@ -298,6 +298,7 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    if (skinny_variant >= 2400) { g_col_silu_x = skinny_variant - 2400; return RT_OK; }            // 2400/2401: gate/up decode GEMM as pairs in 1.5 rounds / as one round of 1.5-pair workgroups
     if (skinny_variant >= 2300) { g_col_rows16 = skinny_variant - 2300; return RT_OK; }           // 2300/2301: <= 16-row decode GEMMs on the 32-row / the 2-workgroups-per-CU 16-row instantiation
     if (skinny_variant >= 2200) { g_prefill_attn_mfma = skinny_variant - 2200; return RT_OK; }    // 2200/2201: prompt attention behind a shared prefix on the vector unit / matrix cores
     if (skinny_variant >= 2100) { g_fuse_conv = skinny_variant - 2100; return RT_OK; }            // 2100/2101: the 96-channel conv pairs of the codec decoder as two launches / one

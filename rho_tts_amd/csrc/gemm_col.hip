@@ -54,12 +54,21 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 // MT = 1 (M <= 16: one of several decode LANES, rt_debug_tune 40n) is held to 128 VGPRs so that two workgroups - of two
 // different lanes' launches - share a CU: two dependent chains can then really run side by side (with one workgroup per CU a
 // second stream's kernel only queues behind the first).
-template <int EPI, int MT, int NPRE>
-__global__ __launch_bounds__(512, ((EPI == COL_SILU && MT == 2) || MT == 1) ? 4 : 2) void k_gemm_col(ColArgs g) {
+// X (gate/up only): the workgroup also owns HALF of a second gate/up pair - 8 gate and 8 up columns side by side in one more
+// 16-column MFMA tile - so that 3 n pairs run as 2 n workgroups of 1.5 pairs each.  The 1.7B talker's 384 pairs are then ONE
+// round of 256 workgroups instead of a full round plus a half-empty one (which costs as much as two: 14.8 us for 384
+// workgroups, 15.8 for 512, 9.6 for 256 - tools/bench_gemm_col_sweep.py), and the extra columns reuse the A fragments already
+// in registers.  Every column is still summed by the same wave split in the same order: the bits do not change.
+constexpr int col_chunk(int epi, int mt, bool x) {                         // k-tiles (32 deep) per super-chunk
+    return epi == COL_SILU ? (x ? (mt == 4 ? 2 : 4) : 2) : ((mt == 4 || mt == 1) ? 4 : 8);
+}
+template <int EPI, int MT, int NPRE, bool X = false>
+__global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && !X) ? 4 : 2) void k_gemm_col(ColArgs g) {
+    static_assert(!X || (EPI == COL_SILU && MT >= 2), "the extra half pair exists for gate/up only");
     __shared__ float red[WAVES][MT][4][64];  // 16 KiB per 32 rows: one 16x16 accumulator tile per sub-block and wave
     __shared__ float sh_inv[16 * MT];        // RMSNorm row scales
-    constexpr int NB = (EPI == COL_SILU) ? 2 : 1;
-    constexpr int C = (NB == 2) ? 2 : ((MT == 4 || MT == 1) ? 4 : 8);     // k-tiles (32 deep) per super-chunk
+    constexpr int NB = (EPI == COL_SILU) ? (X ? 3 : 2) : 1;
+    constexpr int C = col_chunk(EPI, MT, X);
     constexpr int PASSES = (MT + 1) / 2;     // epilogue / row-scale passes of 32 rows (MT = 1: half of one)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, qd = lane >> 4;
@@ -77,7 +86,10 @@ __global__ __launch_bounds__(512, ((EPI == COL_SILU && MT == 2) || MT == 1) ? 4 
 
     const s8_t* wp[NB];
     wp[0] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)nt * g.KT + kt_lo) * 64 + lane;
-    if (NB == 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
+    if (NB >= 2) wp[1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(nt + g.up_tile_offset) * g.KT + kt_lo) * 64 + lane;
+    // the extra tile: lanes r < 8 hold gate columns x_col0 + r of pair x_tile, lanes r >= 8 its up columns x_col0 + r - 8
+    const int x_tile = g.x_tile0 + ((int)blockIdx.x >> 1), x_col0 = ((int)blockIdx.x & 1) * 8;
+    if (NB == 3) wp[NB - 1] = reinterpret_cast<const s8_t*>(g.Wp) + ((int64_t)(x_tile + (r < 8 ? 0 : g.up_tile_offset)) * g.KT + kt_lo) * 64 + qd * 16 + x_col0 + (r & 7);
     // fragment-tiled A, 16-row sub-blocks: this lane's 8 elements of k-tile kt sit at tile_off(row, 32 kt + 8 qd)
     const s8_t* ap[MT];
 #pragma unroll
@@ -248,30 +260,36 @@ __global__ __launch_bounds__(512, ((EPI == COL_SILU && MT == 2) || MT == 1) ? 4 
             if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + blockIdx.x] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
-                const float u = val[NB - 1][ps] * inv;
+                const float u = val[1][ps] * inv;
                 g.out_bf16[tile_off(g.row_off + e_row, n, (int)g.ldc)] = f32_to_bf16(v / (1.f + __expf(-v)) * u);
+            }
+            if (X) {                              // the extra half pair: gate in columns 0..7 of its tile, up in 8..15 of the same row
+                const float gx = val[NB - 1][ps] * inv;
+                const float ux = __shfl_down(gx, 8, 16);
+                const int nx = x_tile * 16 + x_col0 + (e_l & 7);
+                if (e_row < g.M && (e_l & 15) < 8 && nx < g.N) g.out_bf16[tile_off(g.row_off + e_row, nx, (int)g.ldc)] = f32_to_bf16(gx / (1.f + __expf(-gx)) * ux);
             }
         }
     }
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
 }
 
-template <int EPI, int MT, int NPRE>
+template <int EPI, int MT, int NPRE, bool X = false>
 void launch_one(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
-    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
-    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
+    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
+    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, bool X = false>
 void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     // every wave needs at least one k-tile for the clamped (branch-free) requests to be valid addresses
-    constexpr int C = (EPI == COL_SILU) ? 2 : ((MT == 4 || MT == 1) ? 4 : 8);
+    constexpr int C = col_chunk(EPI, MT, X);
     const int kchunk = (g.KT + WAVES - 1) / WAVES;
     const bool all_waves_busy = g.KT >= WAVES && (WAVES - 1) * kchunk < g.KT;
     const int n_sc = (kchunk + C - 1) / C;
-    if (!all_waves_busy) launch_one<EPI, MT, 0>(ctx, g, grid, e0, e1);
-    else if (n_sc >= 2) launch_one<EPI, MT, 2>(ctx, g, grid, e0, e1);
-    else launch_one<EPI, MT, 1>(ctx, g, grid, e0, e1);
+    if (!all_waves_busy) launch_one<EPI, MT, 0, X>(ctx, g, grid, e0, e1);
+    else if (n_sc >= 2) launch_one<EPI, MT, 2, X>(ctx, g, grid, e0, e1);
+    else launch_one<EPI, MT, 1, X>(ctx, g, grid, e0, e1);
 }
 
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
@@ -279,7 +297,10 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
     switch (g.epi) {
         case COL_STORE: wide ? launch_npre<COL_STORE, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_STORE, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_STORE, 2>(ctx, g, grid, e0, e1); break;
         case COL_RESID: wide ? launch_npre<COL_RESID, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_RESID, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_RESID, 2>(ctx, g, grid, e0, e1); break;
-        case COL_SILU: wide ? launch_npre<COL_SILU, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_SILU, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2>(ctx, g, grid, e0, e1); break;
+        case COL_SILU:
+            if (g.x_tile0 > 0) wide ? launch_npre<COL_SILU, 4, true>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2, true>(ctx, g, grid, e0, e1);
+            else wide ? launch_npre<COL_SILU, 4>(ctx, g, grid, e0, e1) : narrow ? launch_npre<COL_SILU, 1>(ctx, g, grid, e0, e1) : launch_npre<COL_SILU, 2>(ctx, g, grid, e0, e1);
+            break;
         default: return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: bad epilogue %d", g.epi);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -290,7 +311,9 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 
 // gate/up GEMM (N = 2 * inter): a workgroup owns a gate tile and its up tile, N/32 workgroups.  Halving the tiles to even out
 // the 1.5 rounds of the 1.7B talker (384 workgroups on 256 CUs) was measured slower (21.5 vs 17.4 us: every workgroup
-// re-reads the whole A operand), so the split is only taken when forced through rt_debug_tune(502/504).
+// re-reads the whole A operand), so that split is only taken when forced through rt_debug_tune(502/504); the 1.5 rounds
+// are evened out the other way - fewer, larger workgroups (X, g_col_silu_x).
+int g_col_silu_x = 1;            // 1: gate/up GEMMs whose pairs are 1.5x the CUs run as one round of 1.5-pair workgroups (rt_debug_tune 2400 / 2401)
 int g_col_rows16 = 0;            // 1: launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU: decode lanes, rt_debug_tune 2301)
 int g_col_split4 = 0;            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
 int col_split_silu(int N, int n_cu) {
@@ -322,6 +345,14 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
         tiles = g.NT / 2;
         g.up_tile_offset = g.NT / 2;
         g.N = w.N / 2;
+        g.x_tile0 = 0;
+        // more pairs than CUs but no more than 1.5x: 2/3 of them as workgroups, each with half of one of the others
+        const int wg = tiles / 3 * 2;
+        const bool narrow = g.M <= 16 && g_col_rows16;
+        if (g_col_silu_x && g.split == 1 && !narrow && tiles % 3 == 0 && tiles > ctx->n_cu && wg <= ctx->n_cu && (w.N / 2) % 16 == 0) {
+            g.x_tile0 = wg;
+            tiles = wg;
+        }
     } else {
         g.N = w.N;
     }

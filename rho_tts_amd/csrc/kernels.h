@@ -100,6 +100,7 @@ extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next
 extern int g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
 extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
 extern int g_col_split4;
+extern int g_col_silu_x;         // 1: 1.5-pair gate/up workgroups when the pairs are 1.5x the CUs
 extern int g_col_rows16;         // 1: <= 16-row decode GEMM launches on the two-workgroups-per-CU instantiation (decode lanes)          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
 int col_split_for(int N, int n_cu);
 int col_split_silu(int N, int n_cu);
@@ -135,6 +136,7 @@ struct ColArgs {
     // filled by the launcher
     const bf16_t* Wp = nullptr;
     int NT = 0, KT = 0, N = 0, up_tile_offset = 0;
+    int x_tile0 = 0;                // gate/up: > 0 = workgroups own 1.5 pairs, the halves come from pairs x_tile0 ...
 };
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)

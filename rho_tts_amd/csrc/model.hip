@@ -1390,7 +1390,7 @@ int rt_gen_run::init(const rt_generate_args* a) {
                 mix((uint64_t)(uintptr_t)p);
                 mix(ln.b0); mix(ln.n);
             }
-        mix(B); mix(col); mix(n_lanes); mix(A.ignore_eos); mix(A.min_frames); mix(g_attn_mfma); mix(g_col_split); mix(g_col_split4); mix(g_col_rows64); mix(g_col_rows16); mix(g_fuse_sample_embed);
+        mix(B); mix(col); mix(n_lanes); mix(A.ignore_eos); mix(A.min_frames); mix(g_attn_mfma); mix(g_col_split); mix(g_col_split4); mix(g_col_rows64); mix(g_col_rows16); mix(g_col_silu_x); mix(g_fuse_sample_embed);
         // the attention nodes carry the voice prefix (slot, length) by value: a voice of another length must not replay the
         // old graphs.  The prefix KV *content* is read through pointers, so re-setting a voice of the same length keeps them.
         mix((uint64_t)Lp); mix((uint64_t)(int64_t)m->talker.kv.prefix_slot);

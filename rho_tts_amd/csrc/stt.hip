@@ -432,8 +432,10 @@ int rt_stt_create(rt_ctx* ctx, const rt_stt_config* cfg, rt_stt** out) {
         c.enc_layers < 1 || c.dec_layers < 1 || c.n_ctx < 2 || c.n_text_ctx < 2 || c.vocab < 2 || c.n_fft < 16 || c.n_fft % 2 || c.hop < 1 ||
         c.sample_rate < 1000 || c.chunk_seconds < 1 || (int64_t)c.chunk_seconds * c.sample_rate / c.hop != 2 * (int64_t)c.n_ctx || c.n_prefix < 1 ||
         c.n_prefix > 8 || c.n_begin_suppress < 0 || c.n_begin_suppress > 4 || c.eos_id < 0 || c.eos_id >= c.vocab || c.max_new_tokens < 1 ||
-        c.n_prefix + c.max_new_tokens > c.n_text_ctx)
+        c.n_prefix + c.max_new_tokens > c.n_text_ctx || c.n_fft > 2048)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_stt_create: unsupported configuration (head_dim in {32,64,128}, widths %% 8, 2 n_ctx = frames of one chunk)");
+    for (int i = 0; i < c.n_prefix; ++i)      // (forced ids index the embedding table)
+        if (c.prefix[i] < 0 || c.prefix[i] >= c.vocab) return rt_fail(ctx, RT_ERR_INVALID, "rt_stt_create: forced prefix id %d outside the vocabulary of %d", c.prefix[i], c.vocab);
     std::lock_guard<std::mutex> g(ctx->mu);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rt_stt* s = new rt_stt();

@@ -124,6 +124,30 @@ def test_gemm_col_sixteen_row_instantiation_is_exact(ctx, M):
         ctx.lib.rt_debug_tune(2300, 0)
 
 
+@pytest.mark.parametrize("M", [8, 17, 32, 33, 64])
+def test_gate_up_one_and_a_half_pairs_per_workgroup_changes_no_bit(ctx, M):
+    """The 1.7B talker's gate/up GEMM has 384 gate/up tile pairs for 256 CUs; by default it runs as 256 workgroups of 1.5 pairs
+    (k_gemm_col<SILU, MT, NPRE, X>: the half pair's 8 gate + 8 up columns share one more MFMA tile).  Every column keeps its wave
+    split and summation order, so the activations equal the one-pair-per-workgroup launch (rt_debug_tune 2400) bit for bit."""
+    N, K = 12288, 2048
+    assert ctx.device_info()["n_cu"] == 256
+    g = torch.Generator().manual_seed(5 + M)
+    x_prev = torch.randn(M, K, generator=g)
+    a = ((1.0 + 0.1 * torch.randn(K, generator=g)) * x_prev).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    sq = (x_prev ** 2).view(M, 8, K // 8).sum(2).cuda()
+    got = run_col(ctx, a, w, SILU, 0, 0, 1, sq, 1e-6)["act"]
+    ctx.lib.rt_debug_tune(2400, 0)
+    try:
+        pairs = run_col(ctx, a, w, SILU, 0, 0, 1, sq, 1e-6)["act"]
+    finally:
+        ctx.lib.rt_debug_tune(2401, 0)
+    assert torch.equal(got, pairs) and float(got.float().abs().max()) > 0.1
+    ref = (a.float() @ w.float().T) * torch.rsqrt((x_prev ** 2).mean(1) + 1e-6).cuda()[:, None]
+    want = torch.nn.functional.silu(ref[:, : N // 2]) * ref[:, N // 2:]
+    assert float((got.float() - want).abs().max()) < 2.0 ** -7 * float(want.abs().max()) + 2e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("N,K,epi,norm,name", SHAPES, ids=[s[4] for s in SHAPES])
 def test_gemm_col_random_operands(ctx, N, K, epi, norm, name):
     """Random bf16 operands, real RMSNorm partials: tolerance 2e-3 of the output scale (f32 accumulation in another order)."""

@@ -142,3 +142,16 @@ def test_transcriber_from_a_checkpoint_directory(ctx, tmp_path):
     finally:
         tr.close()
         ref.close()
+
+
+def test_configurations_the_kernels_cannot_serve_are_refused(ctx):
+    """`rt_stt_create` checks what the kernels index with: a forced id outside the vocabulary (it would read past the embedding
+    table), a chunk that is not 2 n_ctx frames, a head width without an attention instantiation."""
+    import dataclasses
+    cfg = S.tiny_test_config()
+    state = S.synthetic_state(cfg, 789)
+    for bad, what in ((dataclasses.replace(cfg, prefix=(291, cfg.vocab + 5)), "prefix id"),
+                      (dataclasses.replace(cfg, chunk_seconds=3), "unsupported configuration"),
+                      (dataclasses.replace(cfg, heads=4), "unsupported configuration")):
+        with pytest.raises(ValueError, match=what):
+            S.NativeSTT(ctx, bad, state)
