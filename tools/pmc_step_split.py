@@ -60,7 +60,9 @@ def main():
     n_frames_a = acc["predictor heads"][0] / (G - 1)
     n_frames_b = n_b / (t.layers * 4)
     from rho_tts_amd._build import source_hash
-    out = {"source": os.path.basename(src), "build_sha256": source_hash(),        # bench.py reports these bytes only for this very build "k_gemm_col_dispatches": len(rows), "frames_part_a": n_frames_a, "frames_part_b": n_frames_b, "classes": {}}
+    # (build_sha256: bench.py reports these bytes only for this very build)
+    out = {"source": os.path.basename(src), "build_sha256": source_hash(), "k_gemm_col_dispatches": len(rows), "frames_part_a": n_frames_a,
+           "frames_part_b": n_frames_b, "classes": {}}
     tot_f = tot_a = 0.0
     for k, (n, fetched, ns) in acc.items():
         frames = n_frames_b if k == "talker layers" else n_frames_a
