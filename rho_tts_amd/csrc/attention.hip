@@ -36,10 +36,33 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     const int kh = blockIdx.x, row = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int sub = lane % LPP, pg = lane / LPP;
+    // FUSED: the wave's first head vector (q / k / v of the new position) and its norm weights depend on the row only - they are
+    // requested BEFORE the row's position and slot are known, so their round trip overlaps the dependent scalar loads below
+    // (frame -> position / slot) instead of following them; the RoPE factors are requested as soon as the position is known and
+    // not behind the norm's reduction (three dependent memory round trips fewer per launch).
+    constexpr int half = D / 2;
+    const int width = (heads + 2 * kv_heads) * D;
+    const bool act = lane < half;
+    float pa = 0.f, pb = 0.f, pwa = 0.f, pwb = 0.f, pc = 0.f, psn = 0.f;
+    // (branch-free on purpose: clamped lanes / vectors and a stand-in pointer instead of `if`s - behind a divergent branch the
+    //  compiler drains every outstanding load, `s_waitcnt vmcnt(0)`, before it goes on, which would serialise the requests again)
+    const int l0 = act ? lane : 0;
+    if (FUSED) {
+        const int v0 = w < REP + 2 ? w : REP + 1;
+        const int col0 = v0 < REP ? (kh * REP + v0) * D : (v0 == REP ? (heads + kh) * D : (heads + kv_heads + kh) * D);
+        const float* src = q + (int64_t)row * width + col0;
+        pa = src[l0];
+        pb = src[l0 + half];
+        const float* nw = v0 < REP ? qw : kw;
+        const float* nwp = nw ? nw : src;
+        pwa = nwp[l0];
+        pwb = nwp[l0 + half];
+    }
+    const int slot = row_slot[row];
     const int hi = row_pos[row] + pos_add + (frame_ptr ? *frame_ptr : 0);
+    if (FUSED) { pc = cosT[(int64_t)hi * half + l0]; psn = sinT[(int64_t)hi * half + l0]; }
     int lo = 0;
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
-    const int slot = row_slot[row];
     const float scale = rsqrtf((float)D);
     const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
     const bf16_t* kb = kc + base * D + sub * 8;
@@ -75,23 +98,24 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 
     if (FUSED) {
         // vectors of this head group: REP query heads, then K, then V; wave w takes vectors w, w+4, ...
-        constexpr int half = D / 2;
-        const int width = (heads + 2 * kv_heads) * D;
         for (int vec = w; vec < REP + 2; vec += NW) {
             const bool is_q = vec < REP, is_k = vec == REP;
             const int col0 = is_q ? (kh * REP + vec) * D : (is_k ? (heads + kh) * D : (heads + kv_heads + kh) * D);
-            const bool act = lane < half;
-            float a = 0.f, b = 0.f;
-            if (act) { a = q[(int64_t)row * width + col0 + lane]; b = q[(int64_t)row * width + col0 + lane + half]; }
+            const bool first = vec == w;             // (operands of the first vector are already on their way, see the top)
+            float a = pa, b = pb;
+            if (!first && act) { a = q[(int64_t)row * width + col0 + lane]; b = q[(int64_t)row * width + col0 + lane + half]; }
             if (is_q || is_k) {
                 const float* nw = is_q ? qw : kw;
                 if (nw) {
+                    float wa = pwa, wb = pwb;
+                    if (!first && act) { wa = nw[lane]; wb = nw[lane + half]; }
                     const float ss = wave_sum_f32(act ? a * a + b * b : 0.f);
                     const float inv = rsqrtf(ss / (float)D + eps);
-                    if (act) { a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv); }
+                    if (act) { a = wa * (a * inv); b = wb * (b * inv); }
                 }
                 if (act) {
-                    const float c = cosT[(int64_t)hi * half + lane], s = sinT[(int64_t)hi * half + lane];
+                    float c = pc, s = psn;
+                    if (!first) { c = cosT[(int64_t)hi * half + lane]; s = sinT[(int64_t)hi * half + lane]; }
                     const float ra = a * c - b * s, rb = b * c + a * s;
                     a = ra; b = rb;
                 }

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
         // KU code dimensions per step: their codebook values are requested together, so the L2 round trip is paid once per step;
         // the sums themselves run in ascending k, one rounding per operation (oracle/encoder.py rvq_level)
         constexpr int KU = 8;
-        for (int k0 = 0; k0 < D; k0 += KU) {
-            float cv[KU][NE];
+        // ... and the NEXT step's values are requested before this step's sums run (two register sets, the loop unrolled by two):
+        // a level is D / KU dependent L2 round trips otherwise - 512 of them for 16 levels, which is what this kernel's time was
+        auto fetch = [&](int k0, float (&cv)[KU][NE]) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const float* row = cb + (int64_t)(k0 + u < D ? k0 + u : D - 1) * K;
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
                     cv[u][i] = row[j < K ? j : K - 1];          // (clamped, unconditional: the entry is ignored in the argmin)
                 }
             }
+        };
+        auto sums = [&](int k0, const float (&cv)[KU][NE]) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (k0 + u < D) {
@@ -85,6 +88,14 @@ __global__ __launch_bounds__(RVQ_T) void k_rvq(const float* __restrict__ sem, fl
                     }
                 }
             }
+        };
+        float cva[KU][NE], cvb[KU][NE];
+        fetch(0, cva);
+        for (int k0 = 0; k0 < D; k0 += 2 * KU) {
+            fetch(k0 + KU < D ? k0 + KU : k0, cvb);          // (past the end: a repeat request, never summed)
+            sums(k0, cva);
+            fetch(k0 + 2 * KU < D ? k0 + 2 * KU : k0, cva);
+            if (k0 + KU < D) sums(k0 + KU, cvb);
         }
 #pragma unroll
         for (int f = 0; f < RVQ_FT; ++f) {

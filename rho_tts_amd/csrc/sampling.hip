@@ -262,22 +262,41 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
     bool valid[NV];
     // all loads first (independent, in flight together): a load placed after the logits_copy store of the previous
     // element would have to wait for it (possible aliasing) and the loop degenerates into NV serial round trips
+    // (and BRANCH-FREE: clamped indices and a stand-in pointer, the results masked afterwards - behind a per-lane `if (valid)`
+    //  the compiler drains the load queue, `s_waitcnt vmcnt(0)`, after every single request: eight serial round trips, about
+    //  4 us of a 10-us launch, is what the guarded form cost here)
     const float* __restrict__ lg = A.logits + (int64_t)row * V;
     const uint8_t* __restrict__ seen_r = seen;
+    const uint8_t* __restrict__ seen_or_any = seen_r ? seen_r : reinterpret_cast<const uint8_t*>(lg);
+    // the row's forced token and item id (the random stream's key) ride along with the logits instead of costing a dependent
+    // round trip each where they are used
+    const int forced_raw = *(A.forced ? A.forced + row : reinterpret_cast<const int32_t*>(lg));
+    const unsigned item_id = (unsigned)*(A.item_ids ? reinterpret_cast<const int32_t*>(A.item_ids + row) : reinterpret_cast<const int32_t*>(lg));   // (low half)
     uint8_t sn[NV];
+    float raw[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = (w * NV + j) * 64 + lane;
         valid[j] = i < V;
-        v[j] = valid[j] ? 0.f + lg[i] : 0.f;
-        sn[j] = (seen_r && valid[j]) ? seen_r[i] : (uint8_t)0;
+        const int ic = valid[j] ? i : V - 1;
+        raw[j] = lg[ic];
+        sn[j] = seen_or_any[ic];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        v[j] = valid[j] ? 0.f + raw[j] : 0.f;
+        sn[j] = (seen_r && valid[j]) ? sn[j] : (uint8_t)0;
     }
     for (int sb = 1; sb < A.n_slabs; ++sb) {
+        float more[NV];
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = (w * NV + j) * 64 + lane;
-            if (valid[j]) v[j] += lg[sb * slab_stride + i];
+            more[j] = lg[sb * slab_stride + (valid[j] ? i : V - 1)];
         }
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (valid[j]) v[j] += more[j];
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
 
     if (A.stamps && row == 0 && tid == 0) A.stamps[1] = wall_clock64();
     int token = -1;
-    const int forced = A.forced ? A.forced[row] : -1;
+    const int forced = A.forced ? forced_raw : -1;
     bool need_argmax = !A.do_sample;
     if (forced >= 0) {
         token = forced;
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
                     const unsigned long long reach = __ballot(lane < n && mycum >= lim);
                     if (reach) { keep = __builtin_ctzll(reach) + 1; tot = lane_f32(mycum, keep - 1); }
                 }
-                const float u = rt_uniform(A.seed, (unsigned)A.item_ids[row], (unsigned)A.frame, (unsigned)A.group);
+                const float u = rt_uniform(A.seed, item_id, (unsigned)A.frame, (unsigned)A.group);
                 const float target = __fmul_rn(u, tot);
                 const unsigned long long over = __ballot(lane < keep && mycum > target);
                 const int pick_lane = over ? __builtin_ctzll(over) : keep - 1;
