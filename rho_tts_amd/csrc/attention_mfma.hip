@@ -13,6 +13,8 @@
 // version of this kernel slower than the vector-unit one)
 // - the fused prologue (q/k RMSNorm, RoPE, K/V append: one vector per wave), the rows' own suffix positions (vector unit, as
 // k_attention) and the merge of all partial softmax states stay in the same launch.  16 waves: wave w takes prefix block w.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
@@ -367,15 +369,36 @@ __global__ void k_tile_prefix_kv(const bf16_t* __restrict__ kc, const bf16_t* __
     bf16_t* kd = kt + (int64_t)kh * stride;
     bf16_t* vd = vt + (int64_t)kh * stride;
     const int n_blk = (prefix_len + 31) / 32;
-    for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < n_blk * 4096; i += blockDim.x * gridDim.y) {
-        const int e = i & 7, ln = (i >> 3) & 63, tile = (i >> 9) & 7, blk = i >> 12;
+    const int last = prefix_len - 1;
+    // one thread per lane fragment (8 elements, one 16-B store each for K and V): the K fragment is 16 contiguous bytes of a cache
+    // row, the V fragment one column of 8 consecutive rows; rows past the prefix read a clamped row and are zeroed (no branches
+    // around the loads: all nine requests of a thread are in flight together)
+    for (int g = threadIdx.x + blockIdx.y * blockDim.x; g < n_blk * 512; g += blockDim.x * gridDim.y) {
+        const int ln = g & 63, tile = (g >> 6) & 7, blk = g >> 9;
         const int gq = ln >> 4, n = ln & 15;
-        const int kkey = 32 * blk + 8 * (n >> 2) + (n & 3) + 4 * (tile >> 2), kd_ = 32 * (tile & 3) + 8 * gq + e;
-        kd[i] = kkey < prefix_len ? ks[(int64_t)kkey * D + kd_] : (bf16_t)0;
-        const int vkey = 32 * blk + 8 * gq + e, vd_ = 16 * tile + n;
-        vd[i] = vkey < prefix_len ? vs[(int64_t)vkey * D + vd_] : (bf16_t)0;
+        const int kkey = 32 * blk + 8 * (n >> 2) + (n & 3) + 4 * (tile >> 2);
+        u4_t kf = *reinterpret_cast<const u4_t*>(ks + (int64_t)(kkey < prefix_len ? kkey : last) * D + 32 * (tile & 3) + 8 * gq);
+        unsigned short vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int vkey = 32 * blk + 8 * gq + e;
+            vf[e] = vs[(int64_t)(vkey < prefix_len ? vkey : last) * D + 16 * tile + n];
+        }
+        if (kkey >= prefix_len) kf = u4_t{0u, 0u, 0u, 0u};
+        u4_t vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int vkey = 32 * blk + 8 * gq + 2 * e;
+            const unsigned lo16 = vkey < prefix_len ? vf[2 * e] : 0u, hi16 = vkey + 1 < prefix_len ? vf[2 * e + 1] : 0u;
+            vv[e] = lo16 | (hi16 << 16);
+        }
+        *reinterpret_cast<u4_t*>(kd + (int64_t)g * 8) = kf;
+        *reinterpret_cast<u4_t*>(vd + (int64_t)g * 8) = vv;
     }
 }
+
+// one thread per 8-element fragment: 512 fragments per 32-key block and kv head
+inline unsigned tile_grid_y(int prefix_len) { return (unsigned)std::max(1, ((prefix_len + 31) / 32 * 512 + 255) / 256); }
 
 }  // namespace
 
@@ -427,7 +450,7 @@ bool attention_block_prefix_ok(int M, int heads, int kv_heads, int head_dim, int
 }
 int launch_attention_block_prefix(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads, const int32_t* row_slot, const int32_t* row_pos,
                                   KvCache& kv, int layer, bf16_t* out) {
-    hipLaunchKernelGGL(k_tile_prefix_kv, dim3(kv.kv_heads, 8), dim3(256), 0, ctx->stream, kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(),
+    hipLaunchKernelGGL(k_tile_prefix_kv, dim3(kv.kv_heads, tile_grid_y(M)), dim3(256), 0, ctx->stream, kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(),
                        kv.kv_heads, kv.max_pos, kv.prefix_slot_alloc, M, kv.kt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride,
                        kv.vt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride, kv.vt_stride);
     RT_HIP(ctx, hipGetLastError());
@@ -447,7 +470,7 @@ int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len) {
     if (!kv.vt_prefix || !kv.kt_prefix || kv.head_dim != D) return RT_OK;       // (the matrix-core path exists for head_dim 128 only)
     if ((prefix_len + 31) / 32 * 4096 > kv.vt_stride) return rt_fail(ctx, RT_ERR_LENGTH, "prefix of %d rows exceeds the tiled prefix buffers", prefix_len);
     for (int layer = 0; layer < kv.layers; ++layer)
-        hipLaunchKernelGGL(k_tile_prefix_kv, dim3(kv.kv_heads, 8), dim3(256), 0, ctx->stream, kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(),
+        hipLaunchKernelGGL(k_tile_prefix_kv, dim3(kv.kv_heads, tile_grid_y(prefix_len)), dim3(256), 0, ctx->stream, kv.k + layer * kv.layer_stride(), kv.v + layer * kv.layer_stride(),
                            kv.kv_heads, kv.max_pos, kv.prefix_slot_alloc, prefix_len, kv.kt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride,
                            kv.vt_prefix + (int64_t)layer * kv.kv_heads * kv.vt_stride, kv.vt_stride);
     RT_HIP(ctx, hipGetLastError());
