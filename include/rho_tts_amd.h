@@ -385,7 +385,8 @@ RT_API int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32
 /* The decode step's fused attention launch: qkv [M][(heads+2kv)*d] f32 (raw projections), q/k norm weights [d] or NULL,
  * cos/sin [max_pos][d/2]; row r is sequence slot row_slot[r] at position row_pos[r] + pos_add: its K/V row is appended to the
  * caches [slots][kv_heads][max_pos][d] bf16, then it attends to positions [0, pos]; positions < prefix_len are read from
- * prefix_slot (-1: no shared prefix).  out [M][heads*d] bf16 row-major. */
+ * prefix_slot (-1: no shared prefix).  out [M][heads*d] bf16 row-major.  d_row_slot NULL: row r is slot r; d_row_pos NULL: every
+ * row at pos_add (the array-free form of the residual-code predictor's passes). */
 RT_API int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
                                     const float* d_q_norm_w, const float* d_k_norm_w, float eps, const float* d_cos, const float* d_sin,
                                     const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t pos_add, void* d_k, void* d_v,

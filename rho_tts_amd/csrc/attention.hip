@@ -23,7 +23,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
                                                    const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled, int prefix_slot,
                                                    int prefix_len, const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vc_lo,
-                                                   float* __restrict__ out_f32) {
+                                                   float* __restrict__ out_f32, int slot_base) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     constexpr int U = 4;              // positions in flight per lane
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
         pwa = nwp[l0];
         pwb = nwp[l0 + half];
     }
-    const int slot = row_slot[row];
-    const int hi = row_pos[row] + pos_add + (frame_ptr ? *frame_ptr : 0);
+    // (row_slot == nullptr: slot = slot_base + row; row_pos == nullptr: every row at pos_add - the predictor's passes, whose
+    //  positions are known when the launch is recorded: no dependent scalar loads in front of the K / V requests at all)
+    const int slot = row_slot ? row_slot[row] : slot_base + row;
+    const int hi = (row_pos ? row_pos[row] : 0) + pos_add + (frame_ptr ? *frame_ptr : 0);
     if (FUSED) { pc = cosT[(int64_t)hi * half + l0]; psn = sinT[(int64_t)hi * half + l0]; }
     int lo = 0;
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
@@ -246,15 +248,15 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 }
 
 struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len;
-                   const bf16_t *kc_lo = nullptr, *vc_lo = nullptr; float* out_f32 = nullptr; };
+                   const bf16_t *kc_lo = nullptr, *vc_lo = nullptr; float* out_f32 = nullptr; int slot_base = 0; };
 
 template <int D, bool FUSED, int NW, bool LO = false>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -321,10 +323,12 @@ int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr, int out_tiled) {
-    if (attention_mfma_ok(M, heads, kv_heads, head_dim, window, kv))
+                           const int32_t* frame_ptr, int out_tiled, int slot_base) {
+    if (!row_slot && (slot_base < 0 || slot_base + M > kv.slots))
+        return rt_fail(ctx, RT_ERR_INVALID, "attention: rows %d..%d without a slot array do not fit the %d cache slots", slot_base, slot_base + M - 1, kv.slots);
+    if (row_slot && row_pos && attention_mfma_ok(M, heads, kv_heads, head_dim, window, kv))
         return launch_attention_prefix_mfma(ctx, qkv, M, heads, kv_heads, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, kv, layer,
                                             out, frame_ptr, out_tiled);
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr};
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr, slot_base};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

@@ -199,7 +199,8 @@ int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t
                              const float* d_k_norm_w, float eps, const float* d_cos, const float* d_sin, const int32_t* d_row_slot,
                              const int32_t* d_row_pos, int32_t pos_add, void* d_k, void* d_v, int32_t slots, int32_t max_pos,
                              int32_t prefix_slot, int32_t prefix_len, void* d_out_bf16) {
-    if (!ctx || !d_qkv || !d_cos || !d_sin || !d_row_slot || !d_row_pos || !d_k || !d_v || !d_out_bf16 || M < 1)
+    // (d_row_slot == NULL: row i uses slot i; d_row_pos == NULL: every row at pos_add - the array-free form the predictor's passes take)
+    if (!ctx || !d_qkv || !d_cos || !d_sin || !d_k || !d_v || !d_out_bf16 || M < 1)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: null argument");
     if (prefix_slot >= slots || prefix_len < 0 || prefix_len > max_pos) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: bad prefix");
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -218,7 +219,7 @@ int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t
         if (rt) { (void)hipFree(vt); return rt; }
     }
     const int rc = launch_attention_fused(ctx, d_qkv, M, heads, kv_heads, head_dim, d_q_norm_w, d_k_norm_w, eps, d_cos, d_sin, d_row_slot, d_row_pos,
-                                          pos_add, 0, kv, 0, (bf16_t*)d_out_bf16, nullptr, 0);
+                                          pos_add, 0, kv, 0, (bf16_t*)d_out_bf16, nullptr, 0, 0);
     const hipError_t se = hipStreamSynchronize(ctx->stream);
     if (vt) (void)hipFree(vt);
     RT_HIP(ctx, se);

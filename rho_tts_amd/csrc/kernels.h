@@ -204,7 +204,7 @@ int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr = nullptr, int out_tiled = 0);
+                           const int32_t* frame_ptr = nullptr, int out_tiled = 0, int slot_base = -1);   // row_slot == nullptr: slot = slot_base + row; row_pos == nullptr: every row at pos_add
 
 // decode attention with the shared prefix on the matrix cores (attention_mfma.hip): same contract as launch_attention_fused for
 // head_dim 128, 2 query heads per kv head, no window, a shared prefix of >= 64 rows with its transposed V copy in place

@@ -510,7 +510,7 @@ int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor
 // one_row_per_slot = false (the predictor's 2-row first pass): a row must see the K/V another row of the same launch
 // appends, so q/k-norm + RoPE + append run as their own launch before the attention.
 int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
-                 int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr) {
+                 int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr, int slot_base = -1, bool zero_pos = false) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden, sp_h = col_split_for(H, ctx->n_cu), NTh = H / 16 * sp_h, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
@@ -523,8 +523,10 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         a.epi = COL_STORE; a.out = w.qkv; a.ldc = qw; a.split = col_split_for(qw, ctx->n_cu);
         RT_TRY(col_gemm(m, a, L.wqkv, isp));
         if (one_row_per_slot) {
-            RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
-                                          pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1));
+            // (slot_base >= 0: rows sit in consecutive slots; zero_pos: every row at pos_add - the attention then needs no slot /
+            //  position arrays, i.e. no dependent scalar loads in front of its K / V requests)
+            RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, slot_base >= 0 ? nullptr : row_slot,
+                                          zero_pos ? nullptr : row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1, slot_base));
         } else {
             RT_TRY(launch_qkv_post(ctx, w.qkv, 1, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
                                    pos_add, w.q, S.kv, i, frame_ptr));
@@ -1571,7 +1573,7 @@ int rt_gen_run::enqueue_a(Lane& ln) {
             } else if (m->has_mtp()) RT_TRY(launch_gather_f32(ctx, m->proj_emb[q], Hp, codes + q + 1, n, ln.xp, nullptr, G, ln.d_frame, codes_fs));
             else RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs + q + 1, 1, codes + q + 1, n, H, nullptr, nullptr, nullptr, ln.xp, nullptr, G, ln.d_frame, codes_fs));
             if (col) {
-                RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n, ln.d_slot_b, ln.d_zero_pos, q + 2));
+                RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n, ln.d_slot_b, ln.d_zero_pos, q + 2, true, nullptr, ln.b0, true));
             } else {
                 RT_TRY(stack_forward(m, m->pred, ln.wp, ln.xp, n, ln.d_slot_b, ln.d_zero_pos, q + 2, ln.hn_p, nullptr));
             }

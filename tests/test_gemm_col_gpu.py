@@ -326,3 +326,41 @@ def _fused_attention_key_census(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo, pos_
         count = onehot[:n].sum(0)
         want = (count / float(n)).to(torch.bfloat16).float()
         assert torch.equal(got[r], want[None].expand(heads, d)), (r, n, (got[r] - want).abs().max())
+
+
+@pytest.mark.parametrize("pos", [0, 3, 15])
+def test_fused_attention_without_slot_and_position_arrays(ctx, pos):
+    """The residual-code predictor's passes: every row at the same position, row r in slot r - the launch takes NULL for both
+    arrays (no dependent scalar loads in front of its K / V requests).  Same exact census as above, and bit-equal to the launch
+    that is handed the arrays."""
+    d, heads, kvh, max_pos, M = 128, 16, 8, 17, 32
+    g = torch.Generator().manual_seed(11)
+    slots, width = M, (heads + 2 * kvh) * d
+    onehot = torch.eye(d)[torch.arange(max_pos) % d]
+    vc = torch.full((slots, kvh, max_pos, d), 64.0)
+    vc[:, :, :pos] = onehot[:pos]
+    kc = torch.randn(slots, kvh, max_pos, d, generator=g)
+    qkv = torch.zeros(M, width)
+    qkv[:, heads * d: (heads + kvh) * d] = torch.randn(M, kvh * d, generator=g)
+    qkv[:, (heads + kvh) * d:] = onehot[pos].repeat(M, kvh)
+    inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous().cuda(), fr.sin().contiguous().cuda()
+    ones = torch.ones(d).cuda()
+    qkv_d = qkv.cuda()
+    outs = []
+    for arrays in (False, True):
+        kd, vd = kc.to(torch.bfloat16).cuda(), vc.to(torch.bfloat16).cuda()
+        out = torch.zeros(M, heads * d, dtype=torch.bfloat16, device="cuda")
+        slot_d = torch.arange(M, dtype=torch.int32).cuda() if arrays else None
+        pos_d = torch.zeros(M, dtype=torch.int32).cuda() if arrays else None
+        torch.cuda.synchronize()
+        ctx.check(ctx.lib.rt_debug_attention_fused(ctx.handle, ptr(qkv_d), M, heads, kvh, d, ptr(ones), ptr(ones), 1e-6, ptr(cos), ptr(sin), ptr(slot_d),
+                                                   ptr(pos_d), pos, ptr(kd), ptr(vd), slots, max_pos, -1, 0, ptr(out)), "rt_debug_attention_fused")
+        torch.cuda.synchronize()
+        outs.append((out.float().cpu(), kd.float().cpu(), vd.float().cpu()))
+    got = outs[0][0].view(M, heads, d)
+    want = (onehot[: pos + 1].sum(0) / float(pos + 1)).to(torch.bfloat16).float()
+    assert torch.equal(got, want[None, None].expand(M, heads, d))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                   # output and both caches (the appended row) equal the array form
