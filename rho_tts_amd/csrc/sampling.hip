@@ -243,6 +243,28 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
     __shared__ int sh_i[NW];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, V = A.V;
     const int64_t slab_stride = (int64_t)A.M * V;
+    // all loads first (independent, in flight together): a load placed after the logits_copy store of the previous
+    // element would have to wait for it (possible aliasing) and the loop degenerates into NV serial round trips
+    // (and BRANCH-FREE: clamped indices and a stand-in pointer, the results masked afterwards - behind a per-lane `if (valid)`
+    //  the compiler drains the load queue, `s_waitcnt vmcnt(0)`, after every single request: eight serial round trips, about
+    //  4 us of a 10-us launch, is what the guarded form cost here).  They also come BEFORE the frame bookkeeping below: nothing
+    //  they read depends on the frame index, so they need not wait for that scalar round trip.
+    const float* __restrict__ lg = A.logits + (int64_t)row * V;
+    const uint8_t* __restrict__ seen_r = A.seen ? A.seen + (int64_t)row * V : nullptr;
+    const uint8_t* __restrict__ seen_or_any = seen_r ? seen_r : reinterpret_cast<const uint8_t*>(lg);
+    // the row's item id (the random stream's key) rides along instead of costing a dependent round trip where it is used
+    const unsigned item_id = (unsigned)*(A.item_ids ? reinterpret_cast<const int32_t*>(A.item_ids + row) : reinterpret_cast<const int32_t*>(lg));   // (low half)
+    bool valid[NV];
+    uint8_t sn[NV];
+    float raw[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = (w * NV + j) * 64 + lane;
+        valid[j] = i < V;
+        const int ic = valid[j] ? i : V - 1;
+        raw[j] = lg[ic];
+        sn[j] = seen_or_any[ic];
+    }
     if (A.seed_ptr) A.seed = *A.seed_ptr;
     if (A.frame_ptr) {     // graph replay: frame index and frame-strided buffers resolved on the device
         const int f = *A.frame_ptr;
@@ -259,29 +281,8 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
     if (A.stamps && row == 0 && tid == 0) A.stamps[0] = wall_clock64();
     float v[NV];
     unsigned key[NV];
-    bool valid[NV];
-    // all loads first (independent, in flight together): a load placed after the logits_copy store of the previous
-    // element would have to wait for it (possible aliasing) and the loop degenerates into NV serial round trips
-    // (and BRANCH-FREE: clamped indices and a stand-in pointer, the results masked afterwards - behind a per-lane `if (valid)`
-    //  the compiler drains the load queue, `s_waitcnt vmcnt(0)`, after every single request: eight serial round trips, about
-    //  4 us of a 10-us launch, is what the guarded form cost here)
-    const float* __restrict__ lg = A.logits + (int64_t)row * V;
-    const uint8_t* __restrict__ seen_r = seen;
-    const uint8_t* __restrict__ seen_or_any = seen_r ? seen_r : reinterpret_cast<const uint8_t*>(lg);
-    // the row's forced token and item id (the random stream's key) ride along with the logits instead of costing a dependent
-    // round trip each where they are used
+    // (the forced token's array moves with the frame: requested here, still well ahead of its use)
     const int forced_raw = *(A.forced ? A.forced + row : reinterpret_cast<const int32_t*>(lg));
-    const unsigned item_id = (unsigned)*(A.item_ids ? reinterpret_cast<const int32_t*>(A.item_ids + row) : reinterpret_cast<const int32_t*>(lg));   // (low half)
-    uint8_t sn[NV];
-    float raw[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = (w * NV + j) * 64 + lane;
-        valid[j] = i < V;
-        const int ic = valid[j] ? i : V - 1;
-        raw[j] = lg[ic];
-        sn[j] = seen_or_any[ic];
-    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         v[j] = valid[j] ? 0.f + raw[j] : 0.f;
