@@ -369,21 +369,39 @@ __global__ __launch_bounds__(256) void k_final_conv(const bf16_t* __restrict__ h
     const int b = blockIdx.y, t0 = blockIdx.x * 128, tid = threadIdx.x;
     for (int i = tid; i < 7 * C; i += 256) wt[i] = w[i];
     const int C8 = C >> 3;
-    for (int idx = tid; idx < 134 * C8; idx += 256) {
-        const int row = idx / C8, c = (idx - row * C8) * 8, t = t0 - 6 + row;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < T) {
-            const int64_t o = ((int64_t)b * T + t) * C + c;
-            const uint4 h = *reinterpret_cast<const uint4*>(hi + o), l = *reinterpret_cast<const uint4*>(lo + o);
-            const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+    // the window, 16 B of each plane per request, seven requests of a thread in flight together: rows outside the item and the
+    // surplus of the last round read a clamped address and are masked / rewrite the value of the clamped index (no branch around
+    // a load: behind one the compiler waits for every request on its own - seven serial round trips per workgroup)
+    constexpr int IT = 7;
+    const int n_items = 134 * C8;
+    for (int base = 0; base < n_items; base += 256 * IT) {
+        uint4 h[IT], l[IT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[2 * e] = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
-                v[2 * e + 1] = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
-            }
+        for (int u = 0; u < IT; ++u) {
+            int idx = base + u * 256 + tid;
+            idx = idx < n_items ? idx : n_items - 1;
+            const int row = idx / C8, c = (idx - row * C8) * 8;
+            int t = t0 - 6 + row;
+            t = t < 0 ? 0 : (t < T ? t : T - 1);
+            const int64_t o = ((int64_t)b * T + t) * C + c;
+            h[u] = *reinterpret_cast<const uint4*>(hi + o);
+            l[u] = *reinterpret_cast<const uint4*>(lo + o);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tile[row * stride + c + e] = v[e];
+        for (int u = 0; u < IT; ++u) {
+            int idx = base + u * 256 + tid;
+            idx = idx < n_items ? idx : n_items - 1;
+            const int row = idx / C8, c = (idx - row * C8) * 8, t = t0 - 6 + row;
+            const bool in = t >= 0 && t < T;
+            const unsigned hw[4] = {h[u].x, h[u].y, h[u].z, h[u].w}, lw[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = __uint_as_float(hw[e] << 16) + __uint_as_float(lw[e] << 16);
+                const float v1 = __uint_as_float(hw[e] & 0xffff0000u) + __uint_as_float(lw[e] & 0xffff0000u);
+                tile[row * stride + c + 2 * e] = in ? v0 : 0.f;
+                tile[row * stride + c + 2 * e + 1] = in ? v1 : 0.f;
+            }
+        }
     }
     __syncthreads();
     const int s = tid >> 1, half = tid & 1, ch = C >> 1;
