@@ -12,11 +12,32 @@ __global__ __launch_bounds__(256) void k_enc_conv0(const float* __restrict__ pcm
                                                    const float* __restrict__ bias, float* __restrict__ x, bf16_t* __restrict__ hi,
                                                    bf16_t* __restrict__ lo) {
     const int c = threadIdx.x % C, tl = threadIdx.x / C, per = blockDim.x / C;
+    // the channel's taps live in registers; the K samples of an output are requested together, clamped and masked instead of
+    // guarded (a guarded load is waited for on its own: K serial round trips per output).  Same products, same order.
+    constexpr int KMAX = 8;
+    float wr[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) wr[k] = w[c * K + (k < K ? k : K - 1)];
+    const float bias_c = bias[c];
     for (int64_t t = (int64_t)blockIdx.x * per + tl; t < T; t += (int64_t)gridDim.x * per) {
-        float acc = bias[c];
-        for (int k = 0; k < K; ++k) {
-            const int64_t ti = t - (K - 1) + k;
-            if (ti >= 0) acc += w[c * K + k] * pcm[ti];
+        float acc = bias_c;
+        if (K <= KMAX) {
+            float p[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int64_t ti = t - (K - 1) + (k < K ? k : K - 1);
+                p[k] = pcm[ti >= 0 ? ti : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const float term = wr[k] * p[k];
+                if (k < K && t - (K - 1) + k >= 0) acc = acc + term;
+            }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const int64_t ti = t - (K - 1) + k;
+                if (ti >= 0) acc += w[c * K + k] * pcm[ti];
+            }
         }
         const int64_t o = t * C + c;
         x[o] = acc;
