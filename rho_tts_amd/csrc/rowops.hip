@@ -69,6 +69,79 @@ __global__ __launch_bounds__(256) void k_add_rmsnorm(float* __restrict__ x, int 
     }
 }
 
+// The same for H = NV x 1024 with everything a thread needs requested up front (the generic form above leaves its loop by a
+// per-lane `break`, and behind such a branch the compiler waits for each iteration's requests on their own; identical arithmetic).
+template <int NV>
+__global__ __launch_bounds__(256) void k_add_rmsnorm_v(float* __restrict__ x, const float* __restrict__ slabs, int n_slabs, int64_t slab_stride,
+                                                       const float* __restrict__ slab_bias, const float* __restrict__ scale, const float* __restrict__ w,
+                                                       float eps, bf16_t* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    __shared__ float sh[4];
+    constexpr int H = NV * 1024;
+    const int64_t row = blockIdx.x;
+    f4_t* xr = reinterpret_cast<f4_t*>(x + row * H);
+    f4_t keep[NV], a[NV], sc[NV], wv[NV];
+    const f4_t zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+    // (absent vectors are read through a stand-in pointer and replaced afterwards: even a uniform `ptr ? load : const` makes the
+    //  compiler wait for everything in flight where the two paths join)
+    const f4_t* bp = reinterpret_cast<const f4_t*>(slab_bias ? slab_bias : x + row * H);
+    const f4_t* sp_ = reinterpret_cast<const f4_t*>(scale ? scale : x + row * H);
+    const f4_t* wp = reinterpret_cast<const f4_t*>(w ? w : x + row * H);
+    const f4_t* s0 = reinterpret_cast<const f4_t*>(n_slabs > 0 ? slabs + row * H : x + row * H);
+    f4_t t0[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        keep[j] = xr[i];
+        a[j] = bp[i];
+        sc[j] = sp_[i];
+        wv[j] = wp[i];
+        t0[j] = s0[i];                       // the first slab (the only one behind the prompt-prefill GEMMs) rides along
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (!slab_bias) a[j] = zero;
+        if (!scale) sc[j] = one;
+        if (n_slabs > 0) a[j] += t0[j];
+    }
+    const int64_t st4 = slab_stride >> 2;
+    for (int s = 1; s < n_slabs; ++s) {
+        f4_t t[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t[j] = (reinterpret_cast<const f4_t*>(slabs + row * H) + threadIdx.x + j * 256)[s * st4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) a[j] += t[j];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        f4_t v = keep[j];
+        if (n_slabs > 0) {
+            f4_t add = a[j];
+            if (scale) add *= sc[j];
+            v += add;
+            xr[threadIdx.x + j * 256] = v;
+        }
+        keep[j] = v;
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (!w) return;
+    const float tot = block_sum_f32(ss, sh);
+    const float inv = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        f4_t v = keep[j];
+        v[0] = wv[j][0] * (v[0] * inv); v[1] = wv[j][1] * (v[1] * inv); v[2] = wv[j][2] * (v[2] * inv); v[3] = wv[j][3] * (v[3] * inv);
+        if (out_f32) reinterpret_cast<f4_t*>(out_f32 + row * H)[i] = v;
+        if (out_bf16) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            reinterpret_cast<uint2*>(out_bf16 + row * H)[i] = pk;
+        }
+    }
+}
+
 // rowsq[row][0] = sum x^2, rowsq[row][1..n) = 0: seeds the NORM prologue of the column-owner GEMM; optionally also
 // re-tiles the row into the fragment layout (common.h tile_off) the decode GEMMs read.
 __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int H, float* __restrict__ rowsq, int rowsq_n,
@@ -434,8 +507,10 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
                        const float* scale, const float* w, float eps, bf16_t* out_bf16, float* out_f32) {
     if (M <= 0) return RT_OK;
     if (H % 4 || H > 8192) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "rmsnorm: hidden size %d unsupported (multiple of 4, <= 8192)", H);
-    hipLaunchKernelGGL(k_add_rmsnorm, dim3(M), dim3(256), 0, ctx->stream, x, H, slabs, n_slabs, (int64_t)M * H, slab_bias, scale, w,
-                       eps, out_bf16, out_f32);
+    const int64_t st = (int64_t)M * H;
+    if (H == 1024) hipLaunchKernelGGL(k_add_rmsnorm_v<1>, dim3(M), dim3(256), 0, ctx->stream, x, slabs, n_slabs, st, slab_bias, scale, w, eps, out_bf16, out_f32);
+    else if (H == 2048) hipLaunchKernelGGL(k_add_rmsnorm_v<2>, dim3(M), dim3(256), 0, ctx->stream, x, slabs, n_slabs, st, slab_bias, scale, w, eps, out_bf16, out_f32);
+    else hipLaunchKernelGGL(k_add_rmsnorm, dim3(M), dim3(256), 0, ctx->stream, x, H, slabs, n_slabs, st, slab_bias, scale, w, eps, out_bf16, out_f32);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
