@@ -62,7 +62,9 @@ __device__ __forceinline__ f4acc_t mfma16(s8_t a, s8_t b, f4acc_t c) {
 constexpr int col_chunk(int epi, int mt, bool x) {                         // k-tiles (32 deep) per super-chunk
     return epi == COL_SILU ? (x ? (mt == 4 ? 2 : 4) : 2) : ((mt == 4 || mt == 1) ? 4 : 8);
 }
-template <int EPI, int MT, int NPRE, bool X = false>
+// NORM = the launch applies an RMSNorm row scale (g.post_scale), as a compile-time property: its partials are then requested
+// without any branch (see the row-scale block), and launches without a scale carry no requests for them at all.
+template <int EPI, int MT, int NPRE, bool X = false, bool NORM = false>
 __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && !X) ? 4 : 2) void k_gemm_col(ColArgs g) {
     static_assert(!X || (EPI == COL_SILU && MT >= 2), "the extra half pair exists for gate/up only");
     __shared__ float red[WAVES][MT][4][64];  // 16 KiB per 32 rows: one 16x16 accumulator tile per sub-block and wave
@@ -130,7 +132,12 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
     const bool n_ok = n < g.N && e_mine;
     float rq[PASSES][16];                      // rowsq partials of rows 32 ps + 4 w + qd, 16 per lane (<= 256 partials per row)
     constexpr int RQ_MAX = 256;
-    if (g.post_scale) {   // row scales: the 16-lane group (w, qd) owns rows 4w + qd (+ 32 per pass), its lanes split the partials
+    if constexpr (NORM) {   // row scales: the 16-lane group (w, qd) owns rows 4w + qd (+ 32 per pass), its lanes split the partials.
+        // NO runtime branch around these requests: behind `if (g.post_scale)` the compiler merged this block with the summation
+        // below and placed the first add (0 + rq[0][0]) at the join - a `s_waitcnt` for the first partial IN FRONT of the weight
+        // chunks' requests, so every NORM launch (qkv, gate/up, the heads: 222 per frame) began to stream its weights one L2
+        // round trip late.  (Unconditional stand-in requests for the launches WITHOUT a scale were measured too: +0.2-0.4 us on
+        // each of those, more than the NORM launches gain - hence the template parameter.)
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row_i = 32 * ps + 4 * w + qd;
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
     if (NPRE >= 1 || n_sc > 0) issue(0, c0);
     if (NPRE >= 2 || (NPRE == 0 && n_sc > 1)) issue(1, c1);
     __builtin_amdgcn_sched_barrier(0);          // ... and their consumers behind them (the scheduler would hoist the row-scale sums)
-    if (g.post_scale) {
+    if constexpr (NORM) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row_i = 32 * ps + 4 * w + qd;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
     for (int ps = 0; ps < PASSES; ++ps) {
         const int e_row = (2 * ps + (tid >> 8)) * 16 + (e_l >> 4) * 4 + e_i;
         const bool ok = e_row < g.M && n_ok;
-        const float inv = (g.post_scale && e_row < 16 * MT) ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
+        const float inv = (NORM && e_row < 16 * MT) ? sh_inv[e_row] : 1.f;       // (published before the reduce barriers)
         float v = val[0][ps] * inv;
         if (EPI == COL_STORE) {
             if (ok) {
@@ -274,22 +281,32 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
 }
 
-template <int EPI, int MT, int NPRE, bool X = false>
+template <int EPI, int MT, int NPRE, bool X, bool NORM>
 void launch_one(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
-    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
-    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
+    if (!e0 && !e1) hipLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X, NORM>), grid, dim3(512), 0, ctx->stream, g);   // plain launches are what a stream capture records
+    else hipExtLaunchKernelGGL((k_gemm_col<EPI, MT, NPRE, X, NORM>), grid, dim3(512), 0, ctx->stream, e0, e1, 0, g);   // device-side begin/end stamps
 }
 
-template <int EPI, int MT, bool X = false>
-void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
+template <int EPI, int MT, bool X, bool NORM>
+void launch_npre2(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
     // every wave needs at least one k-tile for the clamped (branch-free) requests to be valid addresses
     constexpr int C = col_chunk(EPI, MT, X);
     const int kchunk = (g.KT + WAVES - 1) / WAVES;
     const bool all_waves_busy = g.KT >= WAVES && (WAVES - 1) * kchunk < g.KT;
     const int n_sc = (kchunk + C - 1) / C;
-    if (!all_waves_busy) launch_one<EPI, MT, 0, X>(ctx, g, grid, e0, e1);
-    else if (n_sc >= 2) launch_one<EPI, MT, 2, X>(ctx, g, grid, e0, e1);
-    else launch_one<EPI, MT, 1, X>(ctx, g, grid, e0, e1);
+    if (!all_waves_busy) launch_one<EPI, MT, 0, X, NORM>(ctx, g, grid, e0, e1);
+    else if (n_sc >= 2) launch_one<EPI, MT, 2, X, NORM>(ctx, g, grid, e0, e1);
+    else launch_one<EPI, MT, 1, X, NORM>(ctx, g, grid, e0, e1);
+}
+
+// (the residual epilogue never follows an RMSNorm in this model: one instantiation less per shape)
+template <int EPI, int MT, bool X = false>
+void launch_npre(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
+    if (g.post_scale) {
+        if constexpr (EPI != COL_RESID) launch_npre2<EPI, MT, X, true>(ctx, g, grid, e0, e1);
+    } else {
+        launch_npre2<EPI, MT, X, false>(ctx, g, grid, e0, e1);
+    }
 }
 
 int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEvent_t e1) {
@@ -358,6 +375,7 @@ int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t 
     }
     if (g.epi == COL_RESID && (!g.rowsq_out || g.rowsq_out_n < g.NT * g.split)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: rowsq_out too small");
     if (g.post_scale && (!g.rowsq || g.rowsq_n < 1)) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: row scaling without partials");
+    if (g.post_scale && g.epi == COL_RESID) return rt_fail(ctx, RT_ERR_UNSUPPORTED, "gemm_col: the residual epilogue has no row-scaled instantiation");
     if (g.next_bf16 && !g.next_norm_w) return rt_fail(ctx, RT_ERR_INVALID, "gemm_col: next operand without its norm weight");
     return dispatch_epi(ctx, g, dim3(tiles * g.split), ev_start, ev_stop);
 }
