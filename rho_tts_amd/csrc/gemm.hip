@@ -878,13 +878,37 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
         unsigned char* my = lds + w * F_WAVE;
         const GemmEpi& e = g.e;
         const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)g.Wp2, 0, (unsigned)((int64_t)g.NT2 * g.KT2 * 1024), 0x00020000);
+        // the per-channel constants of this conv's epilogue and the first weight fragments of the 1x1 conv: requested once, together
+        // (inside the row-tile loop they were a dependent round trip per column tile and row tile, and every MFMA of the 1x1 conv
+        // waited for a fragment requested just in front of it)
+        float f_bias[NTT], f_sa[NTT], f_sib[NTT];
+        {
+            const float* bp = e.bias ? e.bias : e.snake_a;           // (stand-in: no branch around a request)
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const int n = nt * 32 + r;
+                f_bias[nt] = bp[n];
+                f_sa[nt] = e.snake_a[n];
+                f_sib[nt] = e.snake_ib[n];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+                if (!e.bias) f_bias[nt] = 0.f;
+        }
+        auto load_b2 = [&](int k2, s8_t (&b)[NTT]) {
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+                b[nt] = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (unsigned)(((nt * g.KT2 + k2) * 64 + lane) * 16), 0, 0));
+        };
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            s8_t b2[2][NTT];
+            load_b2(0, b2[0]);
             // 1. this conv's epilogue (bias, SnakeBeta) into LDS as hi / lo planes, [row][channel]
 #pragma unroll
             for (int nt = 0; nt < NTT; ++nt) {
                 const int n = nt * 32 + r;
-                const float bias = e.bias ? e.bias[n] : 0.f, sa = e.snake_a[n], sib = e.snake_ib[n];
+                const float bias = f_bias[nt], sa = f_sa[nt], sib = f_sib[nt];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float v = acc[mt][nt][i] + bias;
@@ -906,13 +930,13 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
                 for (int i = 0; i < 16; ++i) acc2[0][nt][i] = 0.f;
 #pragma unroll
             for (int k2 = 0; k2 < NTT * 2; ++k2) {
+                if (k2 + 1 < NTT * 2) load_b2(k2 + 1, b2[(k2 + 1) & 1]);          // the next k-step's fragments fly during this step's MFMAs
                 const s8_t a_hi = *reinterpret_cast<const s8_t*>(my + r * F_ROWB + (k2 * 16 + h * 8) * 2);
                 const s8_t a_lo = *reinterpret_cast<const s8_t*>(my + 32 * F_ROWB + r * F_ROWB + (k2 * 16 + h * 8) * 2);
 #pragma unroll
                 for (int nt = 0; nt < NTT; ++nt) {
-                    const s8_t b = __builtin_bit_cast(s8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, (unsigned)(((nt * g.KT2 + k2) * 64 + lane) * 16), 0, 0));
-                    acc2[0][nt] = mfma32(a_hi, b, acc2[0][nt]);
-                    acc2[0][nt] = mfma32(a_lo, b, acc2[0][nt]);
+                    acc2[0][nt] = mfma32(a_hi, b2[k2 & 1][nt], acc2[0][nt]);
+                    acc2[0][nt] = mfma32(a_lo, b2[k2 & 1][nt], acc2[0][nt]);
                 }
             }
             // 3. the 1x1 conv's epilogue on this wave's 32 rows
