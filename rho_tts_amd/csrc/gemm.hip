@@ -265,6 +265,28 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
     const __amdgpu_buffer_rsrc_t r_hi = tile_rsrc(e.out_hi, tb, span), r_lo = tile_rsrc(e.out_lo, tb, span);
     const __amdgpu_buffer_rsrc_t r2_hi = tile_rsrc(e.out2_hi, tb, span), r2_lo = tile_rsrc(e.out2_lo, tb, span);
     const __amdgpu_buffer_rsrc_t r2_bf = tile_rsrc(e.out2_bf16, tb, span), r2_f32 = tile_rsrc(e.out2_f32, tb, span);
+    // the per-column constants of every option, for all of the wave's column tiles, requested together up front through stand-in
+    // pointers (an absent vector reads the bias / a valid address and is ignored): fetched where they are used, each sat behind
+    // its own uniform branch - up to four dependent round trips per 32 x 32 tile, drained one by one
+    float c_bias[NTT], c_sa[NTT], c_sib[NTT], c_scale[NTT], c_s2a[NTT], c_s2ib[NTT];
+    {
+        const bool snake = e.act == ACT_SNAKE, two = (e.out2_hi || e.out2_bf16 || e.out2_f32) && e.act2 != ACT_ELU;
+        const float* any = e.bias ? e.bias : (e.scale ? e.scale : (snake ? e.snake_a : (two ? e.snake2_a : nullptr)));
+        if (any) {
+            const float *p_b = e.bias ? e.bias : any, *p_sc = e.scale ? e.scale : any;
+            const float *p_sa = snake ? e.snake_a : any, *p_sib = snake ? e.snake_ib : any;
+            const float *p_2a = two ? e.snake2_a : any, *p_2ib = two ? e.snake2_ib : any;
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                int n = n0 + (wn * NTT + nt) * 32 + r;
+                n = n < N ? n : N - 1;
+                c_bias[nt] = p_b[n]; c_scale[nt] = p_sc[n]; c_sa[nt] = p_sa[n]; c_sib[nt] = p_sib[n]; c_s2a[nt] = p_2a[n]; c_s2ib[nt] = p_2ib[n];
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTT; ++nt)
+            if (!e.bias) c_bias[nt] = 0.f;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -287,7 +309,7 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
 #pragma unroll
                 for (int i = 0; i < 16; ++i) res[i] = buf_ld_f32(r_res, RT_OFF(i, 4));
             }
-            const float bias = e.bias ? e.bias[n] : 0.f;
+            const float bias = c_bias[nt];
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = acc[mt][nt][i] + bias;
@@ -298,7 +320,7 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
             } else if (e.act == ACT_SNAKE) {
-                const float sa = e.snake_a[n], sib = e.snake_ib[n];
+                const float sa = c_sa[nt], sib = c_sib[nt];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * sa); v[i] = v[i] + sib * sn * sn; }
             } else if (e.act == ACT_CLAMP1) {
@@ -309,7 +331,7 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
                 for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
             }
             if (e.scale) {
-                const float scale = e.scale[n];
+                const float scale = c_scale[nt];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] *= scale;
             }
@@ -339,7 +361,7 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
 #pragma unroll
                     for (int i = 0; i < 16; ++i) v[i] = v[i] > 0.f ? v[i] : expm1f(v[i]);
                 } else {
-                    const float s2a = e.snake2_a[n], s2ib = e.snake2_ib[n];
+                    const float s2a = c_s2a[nt], s2ib = c_s2ib[nt];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { const float sn = __sinf(v[i] * s2a); v[i] = v[i] + s2ib * sn * sn; }
                 }
