@@ -78,6 +78,7 @@ def declare(lib: C.CDLL) -> None:
     lib.rt_code2wav.argtypes = [vp, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, i64, C.POINTER(i64)]
     lib.rt_profile_enable.argtypes = [vp, i32]
     lib.rt_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rt_profile_read_class.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rt_debug_gemm.argtypes = [vp, vp, i32, i64, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32]
     lib.rt_debug_attention.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
     f32 = C.c_float
@@ -555,4 +556,11 @@ class NativeModel:
     def profile_read(self):
         n, ms, by = C.c_int64(), C.c_double(), C.c_double()
         self.ctx.check(self.lib.rt_profile_read(self.handle, C.byref(n), C.byref(ms), C.byref(by)), "rt_profile_read")
+        return n.value, ms.value, by.value
+
+    def profile_read_class(self, cls: int):
+        """(launches, ms, algorithmic bytes) of the recorded decode GEMMs of one weight-stream class: 0 talker layers / codec head /
+        mtp, 1 the predictor's first pass + heads, 2 predictor passes 2.. (Infinity-Cache re-stream)."""
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        self.ctx.check(self.lib.rt_profile_read_class(self.handle, int(cls), C.byref(n), C.byref(ms), C.byref(by)), "rt_profile_read_class")
         return n.value, ms.value, by.value

@@ -308,3 +308,42 @@ def test_c4_corpus_through_the_provider():
         assert run["alone_checked"] >= 8 and run["alone_equal"] == run["alone_checked"], run
         assert run["generate_calls"] == 1 and run["hand_overs"] >= 10, run          # ONE continuous-batching call per pass
         assert run["audio_s"] > 1000.0, run
+
+
+def _bench(args, env=None, launcher=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable] + (launcher or []) + [os.path.join(root, "bench.py")] + args
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=root, env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher must run a job of two ranks (here: two gloo ranks sharing the
+    one GPU of the box - RCCL needs a GPU per rank) and say so in the line; with the nccl backend and one GPU it must fail."""
+    common = ["--steps", "1", "--warmup", "1", "--model", "tiny", "--batch", "4", "--ref-seconds", "1", "--no-cpu-baseline", "--no-roofline"]
+    r, line = _bench(["--gpus", "2", "--backend", "gloo"] + common)
+    assert r.returncode == 0, r.stdout[-1500:] + "\n" + r.stderr[-3000:]
+    assert line["n_gpus"] == 2 and line["ranks"]["world"] == 2 and line["ranks"]["rccl_ranks_seen"] == 2 and line["ranks"]["backend"] == "gloo"
+    assert len(line["ranks"]["devices"]) == 2 and line["config"]["global_batch"] == 8
+    r, line = _bench(["--gpus", "2"] + common)                    # nccl: one GPU per rank or nothing
+    assert r.returncode != 0 and line is None and "GPU(s) visible" in r.stderr
+
+
+def test_bench_one_gpu_direct_and_under_the_launcher_agree():
+    """`python bench.py --gpus 1` and the driver's `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (RCCL group of one
+    rank, every collective of the multi-GPU step taken) measure the same workload: values within 3 %."""
+    common = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    r1, direct = _bench(common)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2, ranked = _bench(common, env={"RHO_TTS_AMD_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"},
+                        launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541"])
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert direct["ranks"]["rccl_ranks_seen"] is None and direct["ranks"]["world"] == 1
+    assert ranked["ranks"] == dict(ranked["ranks"], world=1, backend="nccl", rccl_ranks_seen=1)
+    assert abs(direct["value"] - ranked["value"]) <= 0.03 * direct["value"], (direct["value"], ranked["value"])
