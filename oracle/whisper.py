@@ -95,6 +95,9 @@ def greedy(model, cfg, mel: torch.Tensor, max_new: Optional[int] = None) -> Tupl
     if cfg.suppress_from > 0:
         never[cfg.suppress_from:] = True
         never[cfg.eos_id] = False
+    for t in getattr(cfg, "suppress_tokens", ()):                    # a generation config's `suppress_tokens`
+        if 0 <= int(t) < cfg.vocab and int(t) != cfg.eos_id:
+            never[int(t)] = True
     budget = min(int(max_new or cfg.max_new_tokens), cfg.n_text_ctx - len(cfg.prefix))
     for step in range(budget):
         lg = model(encoder_outputs=enc, decoder_input_ids=torch.tensor([toks])).logits[0, -1].float()
@@ -111,3 +114,23 @@ def greedy(model, cfg, mel: torch.Tensor, max_new: Optional[int] = None) -> Tupl
         out.append(tok)
         toks.append(tok)
     return out, first
+
+
+def transcribe_windows(model, cfg, pcm: np.ndarray, sr: int, max_tokens: Optional[int] = None) -> List[int]:
+    """Audio of any length: consecutive ``chunk_seconds`` windows of the INPUT, each resampled, featurised, encoded and decoded
+    greedily on its own behind the forced prefix (at most ``max_new_tokens`` ids per window), ids concatenated - the definition
+    rt_stt_transcribe implements (the reference's transcribers walk 30-s windows too, stt_validator.py:133-141, at seek positions
+    taken from timestamp tokens, which the forced <|notimestamps|> prefix rules out here: long-form parity is unpinned)."""
+    pcm = np.asarray(pcm, dtype=np.float32)
+    win = int(cfg.chunk_seconds) * int(sr)
+    n_win = max(1, -(-len(pcm) // win))
+    cap = int(max_tokens or n_win * cfg.max_new_tokens)
+    out: List[int] = []
+    for w in range(n_win):
+        if len(out) >= cap:
+            break
+        x = pcm[w * win:(w + 1) * win]
+        x16 = resample(x, sr, cfg.sample_rate) if sr != cfg.sample_rate else x
+        ids, _ = greedy(model, cfg, log_mel(cfg, x16), min(cap - len(out), cfg.max_new_tokens))
+        out += ids
+    return out

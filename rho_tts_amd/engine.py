@@ -235,10 +235,16 @@ class Engine:
     def stream_wav(self, text: str, seed: int = 789, item_id: int = 0, first_chunk: int = 12, chunk: int = 36, cancel_flag=None,
                    max_frames: Optional[int] = None):
         """Raw waveform chunks (GPU float32) of one text while it is still being decoded: every batch of new codec frames is
-        vocoded with ``left_context_frames`` of the frames before it and the context's samples are dropped - the codec decoder's
-        own chunked decode (chunk boundaries where the frames arrive instead of every ``chunk_frames``).  Yields ``(wav, last)``."""
+        vocoded with ``left_context_frames`` of the frames before it - the codec decoder's own chunked decode, with the chunk
+        boundaries where the frames arrive.  The pieces are cut by ABSOLUTE sample position: n frames decode to
+        ``wav_length(n) = n * up - d`` samples (the transposed convs trim both sides; d = 555 for the 1920x decoder), so a piece
+        decoded from frame ``start - ctx`` on begins at sample ``emitted - (start - ctx) * up`` of its decode - the left context
+        regenerates the d samples the previous piece could not produce yet - and the pieces played back to back are exactly
+        ``wav_length(total frames)`` samples, without a gap at the boundaries.  Yields ``(wav, last)``."""
         c = self.cfg.codec
+        up = c.total_upsample
         have: Optional[torch.Tensor] = None
+        emitted = 0                                            # samples handed out so far = absolute position of the next one
         for codes, last in self.stream_codes(text, seed, item_id, first_chunk, chunk, cancel_flag, max_frames):
             if codes.shape[0] == 0:
                 if last:
@@ -248,7 +254,10 @@ class Engine:
             have = codes if have is None else torch.cat([have, codes])
             ctx = c.left_context_frames if start - c.left_context_frames > 0 else start
             w = self.model.code2wav([have[start - ctx:]])[0]
-            yield w[ctx * c.total_upsample:], last
+            off = max(0, emitted - (start - ctx) * up)
+            piece = w[off:]
+            emitted += int(piece.numel())
+            yield piece, last
 
     def plan_batches(self, frames: Sequence[int]) -> List[List[int]]:
         """Batches of ``max_batch`` text indices.  One batch keeps arrival order; more are bucketed by frame budget, longest

@@ -47,6 +47,7 @@ class SttConfig:
     prefix: Tuple[int, ...] = (50258, 50259, 50359, 50363)
     suppress_from: int = 50257           # special tokens (language / task / timestamp ids) are never text
     begin_suppress: Tuple[int, ...] = (220, 50257)
+    suppress_tokens: Tuple[int, ...] = ()  # further ids never produced (a generation config's `suppress_tokens`)
     max_new_tokens: int = 224
 
     @staticmethod
@@ -70,18 +71,33 @@ class SttConfig:
         eos = gen.get("eos_token_id", c.eos_id)
         c.eos_id = int(eos[0] if isinstance(eos, (list, tuple)) else eos)
         start = int(gen.get("decoder_start_token_id", c.prefix[0]))
-        if gen.get("forced_decoder_ids"):
-            c.prefix = (start,) + tuple(int(t) for _, t in sorted(gen["forced_decoder_ids"]) if t is not None)
-        elif gen.get("lang_to_id") and gen.get("task_to_id"):          # newer generation configs name the ids instead
-            c.prefix = (start, int(gen["lang_to_id"].get("<|en|>", start + 1)), int(gen["task_to_id"].get("transcribe", start + 2)))
-            if gen.get("no_timestamps_token_id") is not None:
-                c.prefix += (int(gen["no_timestamps_token_id"]),)
+        # Forced prefix.  The reference transcribes with language="en" (stt_validator.py:137), so position 1 is <|en|> whatever the
+        # checkpoint's default is.  Published generation configs carry `forced_decoder_ids: [[1, null], [2, 50359]]` - a None means
+        # "decided at generation time", not "absent" - next to lang_to_id / task_to_id / no_timestamps_token_id: a None (or missing)
+        # position is filled from those, and the ids they name win over stale forced entries.
+        forced = {int(p_): (None if t is None else int(t)) for p_, t in (gen.get("forced_decoder_ids") or [])}
+        lang, task = gen.get("lang_to_id") or {}, gen.get("task_to_id") or {}
+        nts = gen.get("no_timestamps_token_id")
+        if forced or (lang and task):
+            classic = start == SttConfig.prefix[0]                  # the multilingual vocabulary the defaults describe
+            en = lang.get("<|en|>", forced.get(1))
+            if en is None and classic:
+                en = SttConfig.prefix[1]
+            tr = task.get("transcribe", forced.get(2))
+            if tr is None and classic:
+                tr = SttConfig.prefix[2]
+            nt = nts if nts is not None else forced.get(3)
+            if nt is None and classic:
+                nt = SttConfig.prefix[3]
+            c.prefix = (start,) + tuple(int(t) for t in (en, tr, nt) if t is not None)
         elif start != c.prefix[0]:
             c.prefix = (start,)
         if gen.get("begin_suppress_tokens"):
             c.begin_suppress = tuple(int(t) for t in gen["begin_suppress_tokens"] if 0 <= int(t) < c.vocab)[:4]
         # Whisper's vocabularies put every special id (language, task, timestamps) behind end-of-sequence
         c.suppress_from = c.eos_id if 0 < c.eos_id < c.vocab else 0
+        # `suppress_tokens`: ids never produced (punctuation-only / non-speech tokens and a few specials below end-of-sequence)
+        c.suppress_tokens = tuple(int(t) for t in (gen.get("suppress_tokens") or []) if 0 <= int(t) < c.vocab and int(t) != c.eos_id)
         if gen.get("max_new_tokens"):
             c.max_new_tokens = int(gen["max_new_tokens"])
         c.max_new_tokens = max(1, min(c.max_new_tokens, c.n_text_ctx - len(c.prefix)))
@@ -143,6 +159,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.rt_stt_tensor_info.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(i64), C.POINTER(i32)]
     lib.rt_stt_set_tensor.argtypes = [vp, C.c_char_p, vp, i32, i64, i64, i32]
     lib.rt_stt_finalize.argtypes = [vp]
+    lib.rt_stt_set_suppress.argtypes = [vp, C.POINTER(i32), i32]
     lib.rt_stt_transcribe.argtypes = [vp, vp, i64, i32, C.POINTER(i32), i32, C.POINTER(i32), vp]
     lib.rt_stt_log_mel.argtypes = [vp, vp, i64, i32, vp]
     lib.rt_stt_encode.argtypes = [vp, vp, i64, i32, vp]
@@ -321,6 +338,9 @@ class NativeSTT:
                                                  rows, cols, 1 if t.is_cuda else 0), f"rt_stt_set_tensor({name.value.decode()})")
         if native:
             raise ValueError(f"tensors not consumed by the library: {sorted(native)[:4]}")
+        if cfg.suppress_tokens:
+            ids = (C.c_int32 * len(cfg.suppress_tokens))(*[int(t) for t in cfg.suppress_tokens])
+            ctx.check(self.lib.rt_stt_set_suppress(self.handle, ids, len(cfg.suppress_tokens)), "rt_stt_set_suppress")
         ctx.check(self.lib.rt_stt_finalize(self.handle), "rt_stt_finalize")
 
     def close(self) -> None:
@@ -342,7 +362,9 @@ class NativeSTT:
 
     def transcribe_ids(self, audio, sample_rate: int, max_tokens: Optional[int] = None, first_logits: bool = False):
         x = self._pcm(audio)
-        cap = int(max_tokens or self.cfg.max_new_tokens)
+        # audio longer than one chunk is transcribed window by window (rt_stt_transcribe): room for every window's ids
+        windows = max(1, -(-int(x.numel()) // (int(self.cfg.chunk_seconds) * int(sample_rate))))
+        cap = int(max_tokens or windows * self.cfg.max_new_tokens)
         toks = (C.c_int32 * cap)()
         n = C.c_int32()
         lg = torch.empty(self.cfg.vocab, dtype=torch.float32, device=x.device) if first_logits else None

@@ -130,6 +130,19 @@ def test_checkpoint_directory_round_trip(tmp_path):
     named = dict(whisper_tiny, forced_decoder_ids=None)
     gen = {"lang_to_id": {"<|en|>": 50259, "<|de|>": 50261}, "task_to_id": {"transcribe": 50359, "translate": 50358}, "no_timestamps_token_id": 50363}
     assert S.SttConfig.from_hf(named, gen).prefix == S.SttConfig().prefix
+    # the generation_config.json Whisper checkpoints SHIP has `forced_decoder_ids: [[1, null], [2, 50359]]` (language
+    # decided at generation time) beside the named ids: <|en|> and <|notimestamps|> must not be dropped
+    shipped = dict(gen, forced_decoder_ids=[[1, None], [2, 50359]], suppress_tokens=[1, 2, 7, 50358, 50257, 99999],
+                   begin_suppress_tokens=[220, 50257], max_length=448)
+    c3 = S.SttConfig.from_hf(named, shipped)
+    assert c3.prefix == (50258, 50259, 50359, 50363)
+    assert c3.suppress_tokens == (1, 2, 7, 50358)                  # in range, end-of-sequence never suppressed
+    assert S.SttConfig.from_hf(dict(whisper_tiny, forced_decoder_ids=[[1, None], [2, 50359]])).prefix == (50258, 50259, 50359, 50363)
+    # a German default in the checkpoint's forced ids does not override the reference's language="en"
+    assert S.SttConfig.from_hf(named, dict(gen, forced_decoder_ids=[[1, 50261], [2, 50359], [3, 50363]])).prefix == (50258, 50259, 50359, 50363)
+    # a vocabulary this build knows nothing about: only what the files say
+    other = {"decoder_start_token_id": 900, "vocab_size": 1000, "eos_token_id": 899, "forced_decoder_ids": [[1, None], [2, 905]]}
+    assert S.SttConfig.from_hf(other).prefix == (900, 905)
     back = S.load_checkpoint(cfg, d)
     assert set(back) == set(state)
     for k in state:

@@ -92,6 +92,8 @@ def test_run_in_flight_survives_other_calls_and_is_dropped_cleanly(eng):
     assert c1.shape[0] == 6 and not fin and torch.equal(c1, whole[:6])
     w = eng.model.code2wav([c1])[0]                                   # another entry point using the pool in between
     assert w.numel() == eng.model.wav_length(6)
+    # a launch-plan switch while a generation is in flight is REFUSED (the run keeps the plan it began with) ...
+    assert eng.ctx.lib.rt_debug_tune(200, 0) == _native.RT_ERR_STATE
     with pytest.raises(RuntimeError):
         eng.set_builtin_voice("ryan", "english")                      # RT_ERR_STATE
     run, done = eng.model.generate_step(1000)
@@ -105,6 +107,35 @@ def test_run_in_flight_survives_other_calls_and_is_dropped_cleanly(eng):
     with pytest.raises(RuntimeError):
         eng.model.generate_step(1)                                    # nothing in flight any more
     eng.model.generate_end()                                          # harmless
+    assert eng.ctx.lib.rt_debug_tune(201, 0) == 0                     # ... and accepted once nothing is in flight
+
+
+def test_tuning_from_another_thread_never_lands_inside_a_call(eng):
+    """rt_debug_tune is process-wide; a thread that flips a switch while another thread generates must not
+    change that call's plan mid-way (the switch waits for calls in flight) - the codes stay those of an undisturbed run."""
+    import threading
+    text = "a thread generates while another one keeps flipping switches"
+    whole = eng.generate_codes([text], seed=9, item_ids=[2], max_frames=[24])[0]
+    stop = threading.Event()
+    flips = [0]
+
+    def flip():
+        lib = eng.ctx.lib
+        while not stop.is_set():
+            for code in (200, 201, 700, 701, 800, 801):               # eager / graph frames, 32- / 64-row launches, fused sampler off / on
+                lib.rt_debug_tune(code, 0)
+                flips[0] += 1
+    th = threading.Thread(target=flip, daemon=True)
+    th.start()
+    try:
+        for _ in range(6):
+            assert torch.equal(eng.generate_codes([text], seed=9, item_ids=[2], max_frames=[24])[0], whole)
+    finally:
+        stop.set()
+        th.join(timeout=10)
+        for code in (201, 701, 801):
+            assert eng.ctx.lib.rt_debug_tune(code, 0) == 0
+    assert flips[0] > 0
 
 
 def test_streamed_waveform_equals_oracle_chunked_decode(eng):
@@ -119,17 +150,27 @@ def test_streamed_waveform_equals_oracle_chunked_decode(eng):
     assert chunks[-1][1] and len(chunks) == 4                          # 5 + 9 + 9 + 7 frames
     c = cfg.codec
     q, up = c.num_quantizers, c.total_upsample
-    start, want = 0, []
+    start, want, emitted = 0, [], 0
     for n in (5, 9, 9, 7):
         ctx = c.left_context_frames if start - c.left_context_frames > 0 else start
         with torch.no_grad():
             w = om.code2wav(codes[start - ctx: start + n, :q].T[None])[0]
-        want.append(w[ctx * up:])
+        want.append(w[max(0, emitted - (start - ctx) * up):])     # by absolute sample position: no gap at the boundaries
+        emitted += want[-1].numel()
         start += n
     for (g, _), w in zip(chunks, want):
         assert g.shape == w.shape
         assert float(torch.sqrt(torch.mean((g - w) ** 2))) < 1e-3
     assert float(torch.cat(want).abs().max()) > 0.01
+    # the pieces played back to back ARE the segment: as many samples as one decode of all 30 frames gives, and the same waveform
+    # up to what the bounded left context changes (the decoder's receptive field reaches further back than the context at a cut)
+    with torch.no_grad():
+        whole = om.code2wav(codes[:, :q].T[None])[0]                  # (one decode of all 30 frames: more than the engine's chunk)
+    got = torch.cat([g for g, _ in chunks])
+    assert got.numel() == whole.numel() == eng.model.wav_length(30)
+    assert float(torch.sqrt(torch.mean((got - whole) ** 2))) < 0.05 * float(whole.abs().max())
+    first_n = chunks[0][0].numel()
+    assert float((got[:first_n - 2 * up] - whole[:first_n - 2 * up]).abs().max()) < 0.05 * float(whole.abs().max())
 
 
 def test_provider_streams_sub_segment_chunks():

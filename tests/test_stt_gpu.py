@@ -38,7 +38,8 @@ def check_model(ctx, cfg, clips, sr, max_new):
             enc_g = nat.encode(x, sr).cpu()
             e_rms = float((enc_g - enc_o).pow(2).mean().sqrt() / enc_o.pow(2).mean().sqrt())
             assert e_rms < 2e-4 and float((enc_g - enc_o).abs().max()) < 5e-3 * float(enc_o.abs().max()), ("encoder", e_rms)
-            ids_o, first_o = OW.greedy(model, cfg, mel_o, max_new)
+            _, first_o = OW.greedy(model, cfg, mel_o, max_new)
+            ids_o = OW.transcribe_windows(model, cfg, x, sr, max_new)       # (clips longer than a chunk: window by window)
             ids_g, first_g = nat.transcribe_ids(x, sr, max_tokens=max_new, first_logits=True)
             l_err = float((first_g.cpu() - first_o).abs().max()) / float(first_o.std())
             assert l_err < 2e-3, ("logits", l_err)
@@ -65,6 +66,36 @@ def test_whisper_tiny_dimensions_eight_clips(ctx):
     sr = 24000
     clips = [clip(d, sr, k) for k, d in enumerate((0.8, 1.7, 2.5, 3.3, 4.1, 5.0, 6.4, 9.0))]
     check_model(ctx, cfg, clips, sr, 12)
+
+
+def test_long_audio_is_transcribed_window_by_window(ctx):
+    """a segment longer than one chunk used to be cut to the chunk silently.  5.3 s on 2-s chunks = three windows, each
+    decoded behind the forced prefix: the ids are the concatenation of the oracle's per-window greedy ids, and a `suppress_tokens`
+    list (generation_config.json) removes exactly those ids on both sides."""
+    import dataclasses
+    cfg = S.tiny_test_config()
+    sr = 24000
+    x = clip(5.3, sr, 11)
+    state = S.synthetic_state(cfg, 789)
+    model = OW.build(cfg, state)
+    nat = S.NativeSTT(ctx, cfg, {k: v.cuda() for k, v in state.items()})
+    try:
+        ids = nat.transcribe_ids(x, sr)
+        want = OW.transcribe_windows(model, cfg, x, sr)
+        assert ids == want and len(ids) > cfg.max_new_tokens                 # more than one window's worth
+        one = nat.transcribe_ids(x[: 2 * sr], sr)
+        assert ids[: len(one)] == one                                         # the first window alone gives the same head
+        assert nat.transcribe_ids(x, sr, max_tokens=15) == want[:15]           # the caller's cap spans the windows
+    finally:
+        nat.close()
+    banned = tuple(sorted(set(want)))[:6]                                      # ids the model likes: now never produced
+    cfg2 = dataclasses.replace(cfg, suppress_tokens=banned)
+    nat = S.NativeSTT(ctx, cfg2, {k: v.cuda() for k, v in state.items()})
+    try:
+        ids2 = nat.transcribe_ids(x, sr)
+        assert ids2 == OW.transcribe_windows(model, cfg2, x, sr) and not set(ids2) & set(banned) and ids2 != want
+    finally:
+        nat.close()
 
 
 def test_native_rate_input_skips_the_resampler(ctx):
