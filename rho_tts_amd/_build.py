@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librho_tts_amd.so")
 ARCH = "gfx950"
+PUBLIC_HEADERS = ("rho_tts_amd.h", "rho_tts_amd_debug.h")     # the drop-in boundary; measurement / test entry points
 
 CXXFLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}",
             "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -37,19 +38,19 @@ def sources():
 
 def _deps_mtime() -> float:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "rho_tts_amd.h"))
+    hdrs += [os.path.join(os.path.dirname(HERE), "include", h) for h in PUBLIC_HEADERS]
     hdrs.append(os.path.abspath(__file__))
     return max(os.path.getmtime(h) for h in hdrs)
 
 
 def source_hash() -> str:
-    """SHA-256 over the native sources (csrc/*.hip, csrc/*.h, include/rho_tts_amd.h, the compiler flags): what identifies a BUILD of
+    """SHA-256 over the native sources (csrc/*.hip, csrc/*.h, include/*.h, the compiler flags): what identifies a BUILD of
     the library independently of where and when hipcc ran (the .so itself is rebuilt by every fresh checkout and need not come out
     byte-identical).  profiles/*.json record it; bench.py reports counter figures only for the build they were measured on."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    files.append(os.path.join(os.path.dirname(HERE), "include", "rho_tts_amd.h"))
+    files += [os.path.join(os.path.dirname(HERE), "include", h) for h in PUBLIC_HEADERS]
     for path in files:
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:

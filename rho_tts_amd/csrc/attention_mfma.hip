@@ -422,7 +422,7 @@ int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads
 }
 
 // prompt rows behind a shared prefix (see the kernel's header): the same preconditions as the decode form but q comes prepared
-int g_prefill_attn_mfma = 1;
+rt_knob g_prefill_attn_mfma{1};
 bool attention_prefill_mfma_ok(int heads, int kv_heads, int head_dim, int window, const KvCache& kv) {
     return g_prefill_attn_mfma && head_dim == D && kv.head_dim == D && heads == REP * kv_heads && window <= 0 && !kv.k_lo && kv.prefix_slot >= 0 &&
            kv.vt_prefix && kv.kt_prefix && kv.prefix_len >= 64 && kv.tiles_len == kv.prefix_len && (kv.prefix_len + 31) / 32 * 4096 <= kv.vt_stride;

@@ -6,11 +6,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
-#include "../../include/rho_tts_amd.h"
+#include "../../include/rho_tts_amd_debug.h"
 
 struct rt_ctx {
     int device = 0;
@@ -25,6 +27,20 @@ struct rt_ctx {
     size_t d_scratch_bytes = 0;
     void* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
+};
+
+// Process-wide launch-plan switches (rt_debug_tune) against calls in flight: every entry point that does work holds g_tune_mu
+// SHARED for its whole duration (CtxLock, together with its context's mutex); rt_debug_tune takes it EXCLUSIVELY - so it waits
+// until no call is executing on any context and no call can see a half-changed plan - and refuses while a resumable generation
+// (rt_generate_begin .. rt_generate_end) is in flight on any model (g_runs_in_flight).  The switches themselves are atomics
+// (kernels.h): read relaxed on the launch paths, written only under the exclusive lock.
+typedef std::atomic<int> rt_knob;
+extern std::shared_mutex g_tune_mu;
+extern std::atomic<int> g_runs_in_flight;
+struct CtxLock {
+    std::shared_lock<std::shared_mutex> tune;
+    std::lock_guard<std::mutex> ctx;
+    explicit CtxLock(rt_ctx* c) : tune(g_tune_mu), ctx(c->mu) {}
 };
 
 inline int rt_fail(rt_ctx* ctx, int status, const char* fmt, ...) {

@@ -4,6 +4,9 @@
 
 #include "common.h"
 
+std::shared_mutex g_tune_mu;               // launch-plan switches against calls in flight (common.h, CtxLock)
+std::atomic<int> g_runs_in_flight{0};      // resumable generations between rt_generate_begin and rt_generate_end, all models
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -72,14 +75,14 @@ const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
     if (!ctx) return RT_ERR_INVALID;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RT_OK;
 }
 
 int rt_synchronize(rt_ctx* ctx) {
     if (!ctx) return RT_ERR_INVALID;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
@@ -87,7 +90,7 @@ int rt_synchronize(rt_ctx* ctx) {
 
 int rt_device_info(rt_ctx* ctx, char* arch, size_t arch_cap, int* n_cu, int64_t* hbm_free, int64_t* hbm_total) {
     if (!ctx) return RT_ERR_INVALID;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (arch && arch_cap) snprintf(arch, arch_cap, "%s", ctx->arch);
     if (n_cu) *n_cu = ctx->n_cu;

@@ -52,7 +52,7 @@ int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t M, int
                   int32_t tap_offset, int32_t rows_out, int32_t rows_in, const void* d_w_bf16, int32_t N, const float* d_bias,
                   int32_t act, float* d_out, int32_t mode, int32_t split_k) {
     if (!ctx || !d_a || !d_w_bf16 || !d_out || M < 1 || N < 1 || cin < 8 || taps < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm: bad argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int K = cin * taps;
     bf16_t* packed = nullptr;
@@ -105,7 +105,7 @@ int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, 
                        const int32_t* d_row_pos, int32_t window, const void* d_k, const void* d_v, int32_t slots, int32_t max_pos,
                        void* d_out_bf16) {
     if (!ctx || !d_q || !d_k || !d_v || !d_out_bf16) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention: null argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     KvCache kv;
     kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
@@ -124,7 +124,7 @@ int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32_t K, c
     if (epi < COL_STORE || epi > COL_SILU) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm_col: epi %d", epi);
     if ((epi != COL_SILU && !d_x) || (epi == COL_SILU && (!d_act_bf16 || N % 32)) || (epi == COL_RESID && !d_rowsq_out))
         return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_gemm_col: missing output for epilogue %d", epi);
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int No = epi == COL_SILU ? N / 2 : N;                  // output width
     if (split <= 0) split = epi == COL_SILU ? col_split_silu(N, ctx->n_cu) : col_split_for(N, ctx->n_cu);
@@ -203,7 +203,7 @@ int rt_debug_attention_fused(rt_ctx* ctx, const float* d_qkv, int32_t M, int32_t
     if (!ctx || !d_qkv || !d_cos || !d_sin || !d_k || !d_v || !d_out_bf16 || M < 1)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: null argument");
     if (prefix_slot >= slots || prefix_len < 0 || prefix_len > max_pos) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_fused: bad prefix");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     KvCache kv;
     kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
@@ -234,7 +234,7 @@ int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t
                                int32_t prefix_len, int32_t mode, void* d_out_bf16) {
     if (!ctx || !d_q || !d_row_slot || !d_row_pos || !d_k || !d_v || !d_out_bf16 || M < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_prefill: null argument");
     if (prefix_slot < 0 || prefix_slot >= slots || prefix_len < 1 || prefix_len > max_pos) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_attention_prefill: bad prefix");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     KvCache kv;
     kv.k = (bf16_t*)d_k; kv.v = (bf16_t*)d_v; kv.layers = 1; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
@@ -281,7 +281,7 @@ int rt_debug_attention_prefill(rt_ctx* ctx, const float* d_q, int32_t M, int32_t
 int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, uint64_t seed, int32_t frame,
                     int32_t group, int32_t suppress_from, int32_t allow_token, uint8_t* d_seen, int32_t* d_out) {
     if (!ctx || !d_logits || !sp || !d_out || M < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_debug_sample: null argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int64_t* items = nullptr;
     RT_HIP(ctx, hipMalloc((void**)&items, (size_t)M * 8));
@@ -299,6 +299,10 @@ int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 }
 
 int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
+    // exclusive: waits until no call is executing on any context (CtxLock holds this lock shared), and a resumable generation in
+    // flight keeps the plan it began with - the switch is refused rather than applied under it
+    std::unique_lock<std::shared_mutex> all(g_tune_mu);
+    if (g_runs_in_flight.load() > 0) return RT_ERR_STATE;
     if (skinny_variant >= 2400) { g_col_silu_x = skinny_variant - 2400; return RT_OK; }            // 2400/2401: gate/up decode GEMM as pairs in 1.5 rounds / as one round of 1.5-pair workgroups
     if (skinny_variant >= 2300) { g_col_rows16 = skinny_variant - 2300; return RT_OK; }           // 2300/2301: <= 16-row decode GEMMs on the 32-row / the 2-workgroups-per-CU 16-row instantiation
     if (skinny_variant >= 2200) { g_prefill_attn_mfma = skinny_variant - 2200; return RT_OK; }    // 2200/2201: prompt attention behind a shared prefix on the vector unit / matrix cores
@@ -331,7 +335,7 @@ int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
 int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t split_k, int32_t n_mats, int32_t iters, double* avg_us,
                          int32_t* used_split) {
     if (!ctx || !avg_us || M < 1 || M > 64 || N < 32 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_skinny: bad argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pb = packed_bytes(N, K);
     bf16_t* wbuf = nullptr;
@@ -367,7 +371,7 @@ int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t s
 int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_norm, int32_t epi, int32_t n_mats, int32_t iters,
                       double* avg_us, int64_t* stamps8) {
     if (!ctx || !avg_us || M < 1 || M > 64 || N < 64 || K < 16 || K % 16 || n_mats < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_gemm_col: bad argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pb = packed_bytes(N, K);
     bf16_t* wbuf = nullptr;
@@ -429,7 +433,7 @@ int rt_bench_gemm_col(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t a_no
 // captured hipGraph replayed `reps` times.  Returns microseconds per launch.
 int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use_graph, int32_t reps, double* us_per_launch) {
     if (!ctx || !us_per_launch || grid_wgs < 1 || n < 1 || reps < 1) return RT_ERR_INVALID;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float* buf = nullptr;
     const int elems = grid_wgs * 256;
@@ -473,7 +477,7 @@ int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use_graph,
 int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, int32_t iters, double* avg_us,
                     int64_t* stamps8) {
     if (!ctx || !d_logits || !sp || !avg_us || M < 1 || iters < 1) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_sample: bad argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int64_t* items = nullptr;
     int32_t* out = nullptr;
@@ -509,7 +513,7 @@ int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
 // abort flag: non-zero = the grid was not co-resident or a spin bound was hit).
 int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, int32_t mode, double* us_per_barrier, int32_t* aborted) {
     if (!ctx || !us_per_barrier || wgs < 1 || threads < 64 || threads > 1024 || n < 1) return RT_ERR_INVALID;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int per_cu = 0;
     auto kern = mode == 2 ? k_bench_barrier<2> : (mode == 1 ? k_bench_barrier<1> : k_bench_barrier<0>);

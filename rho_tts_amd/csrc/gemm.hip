@@ -1001,31 +1001,31 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
     return RT_OK;
 }
 
-int g_pred_nt = 0;              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
-int g_use_graph = 1;            // 1: the decode frame is replayed from captured hipGraphs
-int g_col_rows64 = 1;           // 1: one 64-row decode GEMM launch for the predictor's two-position pass, 0: two 32-row launches
-int g_fuse_sample_embed = 1;    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
-int g_prefill_fill = 3;          // workgroups per CU a prefill GEMM's split-K aims for
-int g_xcd_order = 1;             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
-int g_final_conv = 1;           // 1: the codec decoder's last conv runs in its own LDS-window kernel
-int g_col_max_rows = 64;         // batches up to this many rows decode on the column-owner path (tune 20nn).  Above 32 the talker's GEMMs take 64 rows per
+rt_knob g_pred_nt{0};              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
+rt_knob g_use_graph{1};            // 1: the decode frame is replayed from captured hipGraphs
+rt_knob g_col_rows64{1};           // 1: one 64-row decode GEMM launch for the predictor's two-position pass, 0: two 32-row launches
+rt_knob g_fuse_sample_embed{1};    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
+rt_knob g_prefill_fill{3};          // workgroups per CU a prefill GEMM's split-K aims for
+rt_knob g_xcd_order{1};             // 1: tiled GEMMs run a row tile's column tiles back to back on one XCD
+rt_knob g_final_conv{1};           // 1: the codec decoder's last conv runs in its own LDS-window kernel
+rt_knob g_col_max_rows{64};         // batches up to this many rows decode on the column-owner path (tune 20nn).  Above 32 the talker's GEMMs take 64 rows per
                                 // launch and the predictor's two-position first pass runs as two 64-row launches: 715 audio-s/s at batch 64 against
                                 // 510 at batch 32 (1.7B, bench.py --batch 64) - every weight byte serves twice the rows for ~1.4x the launch time
-int g_conv_tall = 1;            // 1: 256-row tiles for the k>1 convs of the 96- / 192-channel stages
-int g_conv_win = 1;             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
-int g_tile96 = 1;               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
-int g_col_split = 0;            // 0: automatic (col_split_for), else forced 1 / 2 / 4
-int g_attn_mfma = 0;             // 1: the talker's decode attention runs its shared-prefix part on the matrix cores (attention_mfma.hip);
+rt_knob g_conv_tall{1};            // 1: 256-row tiles for the k>1 convs of the 96- / 192-channel stages
+rt_knob g_conv_win{1};             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
+rt_knob g_tile96{1};               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
+rt_knob g_col_split{0};            // 0: automatic (col_split_for), else forced 1 / 2 / 4
+rt_knob g_attn_mfma{0};             // 1: the talker's decode attention runs its shared-prefix part on the matrix cores (attention_mfma.hip);
                                 // measured 16.6 us per launch against 13.3 us for the vector-unit kernel at batch 32 / 460 prefix rows, so off
-int g_handover_every = 4;       // queued items (n_items > rows): frames between two looks at the flags + row hand-overs.  Measured on the
+rt_knob g_handover_every{4};       // queued items (n_items > rows): frames between two looks at the flags + row hand-overs.  Measured on the
                                 // 1.7B model, 512 / 64 ragged texts on 32 rows: 2 -> 487 / 445, 3 -> 489 / 445, 4 -> 491 / 447, 6 -> 485 / 445,
                                 // 8 -> 477 / 428, 12 -> 475 / 434 audio-s/s (a hand-over costs ~1.4 ms, a waiting row 0.13 ms per frame)
-int g_eos_check_every = 8;      // frames between two host looks at the device-side end-of-sequence flags (1 = every frame)
-int g_sync_parts = 0;           // 1: rt_generate waits for the stream after every frame part (bounds the dispatches in flight; profiling aid)
-int g_decode_lanes = 1;         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
-int g_decode_col = 1;           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
-int g_skinny_variant = 0;       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
-int g_skinny_waves_per_cu = 4;  // split-K is chosen so that about this many waves per CU stream weights
+rt_knob g_eos_check_every{8};      // frames between two host looks at the device-side end-of-sequence flags (1 = every frame)
+rt_knob g_sync_parts{0};           // 1: rt_generate waits for the stream after every frame part (bounds the dispatches in flight; profiling aid)
+rt_knob g_decode_lanes{1};         // decode lanes: groups of items decoding concurrently on their own streams (rt_generate)
+rt_knob g_decode_col{1};           // 1: decode stacks use the column-owner GEMM + fused attention (5 launches per layer)
+rt_knob g_skinny_variant{0};       // 0: k_gemm_skinny, 1: k_gemm_skinny2<.,4>, 2: k_gemm_skinny2<.,8>
+rt_knob g_skinny_waves_per_cu{4};  // split-K is chosen so that about this many waves per CU stream weights
 
 int skinny_pick_split(int M, int N, int K, int n_cu) {
     const int tiles = (N + 31) / 32, KT = (K + 15) / 16;
@@ -1075,7 +1075,7 @@ int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, 
     return RT_OK;
 }
 
-int g_prefill_mid = 1;           // 1: prompt prefills of 65..1024 rows run their GEMMs on k_gemm_mid (no split-K slabs); 2 / 3 force its 64 / 128 tiles
+rt_knob g_prefill_mid{1};           // 1: prompt prefills of 65..1024 rows run their GEMMs on k_gemm_mid (no split-K slabs); 2 / 3 force its 64 / 128 tiles
 bool gemm_mid_shape_ok(const PackedW& w) { return g_prefill_mid && w.K % MID_BK == 0 && w.K >= 128 && w.Kp == w.K; }
 bool gemm_mid_ok(int M, const PackedW& w) { return gemm_mid_shape_ok(w) && M > 64 && M <= 1024; }
 int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc) {
@@ -1102,7 +1102,7 @@ int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float
     return RT_OK;
 }
 
-int g_fuse_conv = 1;            // 1: a 96-channel k>1 conv and the 1x1 conv behind its activation run as one launch (launch_conv_pair)
+rt_knob g_fuse_conv{1};            // 1: a 96-channel k>1 conv and the 1x1 conv behind its activation run as one launch (launch_conv_pair)
 
 // a k > 1 conv with SnakeBeta whose hi / lo output planes feed only the 1x1 conv (w2, e2): both in one launch when the first
 // conv's workgroup tile holds every output channel (96 channels, the LDS-window kernel) - else two launches through the planes

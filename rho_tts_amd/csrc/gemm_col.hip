@@ -330,12 +330,12 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 // the 1.5 rounds of the 1.7B talker (384 workgroups on 256 CUs) was measured slower (21.5 vs 17.4 us: every workgroup
 // re-reads the whole A operand), so that split is only taken when forced through rt_debug_tune(502/504); the 1.5 rounds
 // are evened out the other way - fewer, larger workgroups (X, g_col_silu_x).
-int g_col_silu_x = 1;            // 1: gate/up GEMMs whose pairs are 1.5x the CUs run as one round of 1.5-pair workgroups (rt_debug_tune 2400 / 2401)
-int g_col_rows16 = 0;            // 1: launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU: decode lanes, rt_debug_tune 2301)
-int g_col_split4 = 0;            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
+rt_knob g_col_silu_x{1};            // 1: gate/up GEMMs whose pairs are 1.5x the CUs run as one round of 1.5-pair workgroups (rt_debug_tune 2400 / 2401)
+rt_knob g_col_rows16{0};            // 1: launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU: decode lanes, rt_debug_tune 2301)
+rt_knob g_col_split4{0};            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
 int col_split_silu(int N, int n_cu) {
     (void)N; (void)n_cu;
-    return (g_col_split == 2 || g_col_split == 4) ? g_col_split : 1;
+    return (g_col_split == 2 || g_col_split == 4) ? g_col_split.load() : 1;
 }
 
 // sub-tile split for an N-wide decode GEMM: enough workgroups to put one on every CU

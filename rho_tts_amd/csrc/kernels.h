@@ -72,9 +72,9 @@ int launch_pack_weight16(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t*
 // out_hi / out_lo planes are then not written)
 int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW* w2 = nullptr, const GemmEpi* e2 = nullptr);
 bool conv_pair_fusable(const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW& w2);
-extern int g_fuse_conv;
+extern rt_knob g_fuse_conv;
 // prompt-prefill GEMM (65..1024 rows): out[M][N] f32 = A[M][K] bf16 . W^T, whole K per 64 x 64 tile, final sums (no slabs)
-extern int g_prefill_mid;
+extern rt_knob g_prefill_mid;
 bool gemm_mid_ok(int M, const PackedW& w);
 bool gemm_mid_shape_ok(const PackedW& w);     // the weight's shape alone (any row count can then be served in chunks of <= 1024 rows)
 int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float* out, int64_t ldc);
@@ -82,30 +82,30 @@ int launch_gemm_mid(rt_ctx* ctx, const bf16_t* A, int M, const PackedW& w, float
 int launch_gemm_skinny(rt_ctx* ctx, const bf16_t* d_a, int M, const PackedW& w, float* d_out, int64_t ldc, int split_k,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int64_t slab_stride = 0);   // slab s at d_out + s * slab_stride (0: M * ldc)
 int skinny_pick_split(int M, int N, int K, int n_cu);
-extern int g_decode_col;
-extern int g_use_graph;
-extern int g_pred_nt;
-extern int g_decode_lanes;
-extern int g_sync_parts;
-extern int g_eos_check_every;
-extern int g_handover_every;
-extern int g_conv_tall;
-extern int g_col_max_rows;
-extern int g_tile96;
-extern int g_conv_win;
-extern int g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
-extern int g_xcd_order;
-extern int g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
-extern int g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
-extern int g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
-extern int g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
-extern int g_col_split4;
-extern int g_col_silu_x;         // 1: 1.5-pair gate/up workgroups when the pairs are 1.5x the CUs
-extern int g_col_rows16;         // 1: <= 16-row decode GEMM launches on the two-workgroups-per-CU instantiation (decode lanes)          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
+extern rt_knob g_decode_col;
+extern rt_knob g_use_graph;
+extern rt_knob g_pred_nt;
+extern rt_knob g_decode_lanes;
+extern rt_knob g_sync_parts;
+extern rt_knob g_eos_check_every;
+extern rt_knob g_handover_every;
+extern rt_knob g_conv_tall;
+extern rt_knob g_col_max_rows;
+extern rt_knob g_tile96;
+extern rt_knob g_conv_win;
+extern rt_knob g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
+extern rt_knob g_xcd_order;
+extern rt_knob g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
+extern rt_knob g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
+extern rt_knob g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
+extern rt_knob g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
+extern rt_knob g_col_split4;
+extern rt_knob g_col_silu_x;         // 1: 1.5-pair gate/up workgroups when the pairs are 1.5x the CUs
+extern rt_knob g_col_rows16;         // 1: <= 16-row decode GEMM launches on the two-workgroups-per-CU instantiation (decode lanes)          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
 int col_split_for(int N, int n_cu);
 int col_split_silu(int N, int n_cu);
-extern int g_skinny_variant;        // tuning knobs (rt_debug_tune)
-extern int g_skinny_waves_per_cu;
+extern rt_knob g_skinny_variant;        // tuning knobs (rt_debug_tune)
+extern rt_knob g_skinny_waves_per_cu;
 
 // Column-owner decode GEMM (gemm_col.hip): whole-K per workgroup, fused RMSNorm prologue and residual / SwiGLU epilogues.
 enum { COL_STORE = 0, COL_RESID = 1, COL_SILU = 2 };
@@ -208,14 +208,14 @@ int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int 
 
 // decode attention with the shared prefix on the matrix cores (attention_mfma.hip): same contract as launch_attention_fused for
 // head_dim 128, 2 query heads per kv head, no window, a shared prefix of >= 64 rows with its transposed V copy in place
-extern int g_attn_mfma;
+extern rt_knob g_attn_mfma;
 bool attention_mfma_ok(int M, int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
 int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, const float* q_norm_w, const float* k_norm_w, float eps,
                                  const float* rope_cos, const float* rope_sin, const int32_t* row_slot, const int32_t* row_pos, int pos_add,
                                  const KvCache& kv, int layer, bf16_t* out, const int32_t* frame_ptr, int out_tiled);
 int launch_transpose_prefix_v(rt_ctx* ctx, KvCache& kv, int prefix_len);
 // prompt rows (q prepared by launch_qkv_post, K / V appended) behind a shared prefix on the matrix cores: bf16 out [M][heads * d]
-extern int g_prefill_attn_mfma;
+extern rt_knob g_prefill_attn_mfma;
 bool attention_prefill_mfma_ok(int heads, int kv_heads, int head_dim, int window, const KvCache& kv);
 // the prefix slot's own prefill: tiles layer `layer` of the prefix, then causal attention of its M consecutive rows on those tiles
 bool attention_block_prefix_ok(int M, int heads, int kv_heads, int head_dim, int window, const KvCache& kv);

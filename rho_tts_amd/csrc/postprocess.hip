@@ -477,7 +477,7 @@ int post_impl(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32
     if (n_items == 0) return RT_OK;
     if (p->window < 2 || p->fade < 0 || p->crossfade < 0 || p->pause < 0 || p->sample_rate <= 0)
         return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: bad geometry (window=%d fade=%d)", p->window, p->fade);
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const int n_seg = first[n_items];
     if (first[0] != 0 || n_seg < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_post_process: item_first_seg must start at 0");
@@ -588,7 +588,7 @@ int rt_post_process_host(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, 
 int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out) {
     if (!ctx || n < 0 || (n > 0 && (!d_in || !d_out))) return rt_fail(ctx, RT_ERR_INVALID, "rt_pcm16: null argument");
     if (n == 0) return RT_OK;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -603,7 +603,7 @@ int rt_stream_chunk(rt_ctx* ctx, const rt_post_params* p, const float* d_in, int
     if (p->window < 2 || p->fade < 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_stream_chunk: bad geometry (window=%d fade=%d)", p->window, p->fade);
     *h_out_len = 0;
     if (n == 0) return RT_OK;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     void *dv = nullptr, *hv = nullptr;
     RT_TRY_POST(rt_ctx_scratch(ctx, sizeof(StreamState), &dv));

@@ -202,6 +202,7 @@ struct rt_stt {
     float *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *dq = nullptr, *dao = nullptr, *dff = nullptr;
     int32_t *pos_seq = nullptr, *pos_last = nullptr, *slot0 = nullptr, *d_tok = nullptr, *d_gmax = nullptr;
     uint8_t* d_mask = nullptr;
+    std::vector<int32_t> suppress_ids;   // rt_stt_set_suppress: ids never produced (a generation config's `suppress_tokens`)
     std::vector<void*> owned;
 };
 
@@ -436,7 +437,7 @@ int rt_stt_create(rt_ctx* ctx, const rt_stt_config* cfg, rt_stt** out) {
         return rt_fail(ctx, RT_ERR_INVALID, "rt_stt_create: unsupported configuration (head_dim in {32,64,128}, widths %% 8, 2 n_ctx = frames of one chunk)");
     for (int i = 0; i < c.n_prefix; ++i)      // (forced ids index the embedding table)
         if (c.prefix[i] < 0 || c.prefix[i] >= c.vocab) return rt_fail(ctx, RT_ERR_INVALID, "rt_stt_create: forced prefix id %d outside the vocabulary of %d", c.prefix[i], c.vocab);
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     rt_stt* s = new rt_stt();
     s->ctx = ctx;
@@ -449,7 +450,7 @@ int rt_stt_create(rt_ctx* ctx, const rt_stt_config* cfg, rt_stt** out) {
 int rt_stt_destroy(rt_stt* s) {
     if (!s) return RT_OK;
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& sl : s->slots) { if (sl.raw) (void)hipFree(sl.raw); if (sl.raw2) (void)hipFree(sl.raw2); }
@@ -473,7 +474,7 @@ int rt_stt_tensor_info(rt_stt* s, int32_t index, char* name, size_t name_cap, in
 int rt_stt_set_tensor(rt_stt* s, const char* name, const void* data, int32_t dtype, int64_t rows, int64_t cols, int32_t on_device) {
     if (!s || !name || !data) return rt_fail(s ? s->ctx : nullptr, RT_ERR_INVALID, "rt_stt_set_tensor: null argument");
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     SttSlot* sl = stt_find(s, name);
     if (!sl) return rt_fail(ctx, RT_ERR_INVALID, "rt_stt_set_tensor: unknown tensor '%s'", name);
@@ -516,7 +517,7 @@ int rt_stt_set_tensor(rt_stt* s, const char* name, const void* data, int32_t dty
 int rt_stt_finalize(rt_stt* s) {
     if (!s) return RT_ERR_INVALID;
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (s->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_stt_finalize: already finalized");
     for (auto& sl : s->slots)
@@ -555,6 +556,8 @@ int rt_stt_finalize(rt_stt* s) {
         if (c.suppress_from > 0 && i >= c.suppress_from && i != c.eos_id) mask[i] |= 1;
     for (int i = 0; i < c.n_begin_suppress; ++i)
         if (c.begin_suppress[i] >= 0 && c.begin_suppress[i] < c.vocab) mask[c.begin_suppress[i]] |= 2;
+    for (int32_t id : s->suppress_ids)
+        if (id >= 0 && id < c.vocab && id != c.eos_id) mask[id] |= 1;
     ST_TRY(stt_alloc(s, (size_t)c.vocab, &s->d_mask));
     RT_HIP(ctx, hipMemcpy(s->d_mask, mask.data(), c.vocab, hipMemcpyHostToDevice));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -565,7 +568,7 @@ int rt_stt_finalize(rt_stt* s) {
 int rt_stt_log_mel(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate, float* d_mel) {
     if (!s || !d_mel || n_samples < 0 || (n_samples > 0 && !d_pcm) || sample_rate < 1000) return rt_fail(s ? s->ctx : nullptr, RT_ERR_INVALID, "rt_stt_log_mel: bad argument");
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!s->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_stt_log_mel: not finalized");
     ST_TRY(stt_features(s, d_pcm, n_samples, sample_rate));
@@ -577,7 +580,7 @@ int rt_stt_log_mel(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sam
 int rt_stt_encode(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate, float* d_states) {
     if (!s || !d_states || n_samples < 0 || (n_samples > 0 && !d_pcm) || sample_rate < 1000) return rt_fail(s ? s->ctx : nullptr, RT_ERR_INVALID, "rt_stt_encode: bad argument");
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!s->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_stt_encode: not finalized");
     ST_TRY(stt_features(s, d_pcm, n_samples, sample_rate));
@@ -587,33 +590,51 @@ int rt_stt_encode(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t samp
     return RT_OK;
 }
 
+int rt_stt_set_suppress(rt_stt* s, const int32_t* h_ids, int32_t n) {
+    if (!s || n < 0 || (n > 0 && !h_ids)) return rt_fail(s ? s->ctx : nullptr, RT_ERR_INVALID, "rt_stt_set_suppress: bad argument");
+    rt_ctx* ctx = s->ctx;
+    CtxLock g(ctx);
+    if (s->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_stt_set_suppress: call before rt_stt_finalize (the mask is built there)");
+    s->suppress_ids.assign(h_ids, h_ids + n);
+    return RT_OK;
+}
+
+// Audio longer than one chunk is transcribed window by window (consecutive chunk_seconds windows of the INPUT, each through the
+// resampler, the log-mel front-end, the encoder and its own greedy decode behind the forced prefix) and the ids are concatenated:
+// the whole clip is heard, as with the reference's transcribers (faster-whisper walks 30-s windows, stt_validator.py:133-141),
+// though not at their seek positions - those follow timestamp tokens, which the forced <|notimestamps|> prefix rules out.
 int rt_stt_transcribe(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate, int32_t* h_tokens, int32_t max_tokens, int32_t* h_n_tokens,
                       float* d_first_logits) {
     if (!s || !h_tokens || !h_n_tokens || max_tokens < 1 || n_samples < 0 || (n_samples > 0 && !d_pcm) || sample_rate < 1000)
         return rt_fail(s ? s->ctx : nullptr, RT_ERR_INVALID, "rt_stt_transcribe: bad argument");
     rt_ctx* ctx = s->ctx;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    CtxLock g(ctx);
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!s->finalized) return rt_fail(ctx, RT_ERR_STATE, "rt_stt_transcribe: not finalized");
     const rt_stt_config& c = s->cfg;
     *h_n_tokens = 0;
-    ST_TRY(stt_features(s, d_pcm, n_samples, sample_rate));
-    ST_TRY(stt_encode(s));
-    // forced prefix in one pass, then one token per pass: the host reads each token (end-of-sequence decides when to stop)
-    RT_HIP(ctx, hipMemcpyAsync(s->d_tok, c.prefix, c.n_prefix * 4, hipMemcpyHostToDevice, ctx->stream));
-    ST_TRY(stt_decode_rows(s, c.n_prefix, 0));
-    if (d_first_logits) RT_HIP(ctx, hipMemcpyAsync(d_first_logits, s->logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    const int budget = std::min(std::min(max_tokens, c.max_new_tokens), c.n_text_ctx - c.n_prefix);
+    const int64_t win = (int64_t)c.chunk_seconds * sample_rate;     // one window, in input samples
     int n = 0;
-    for (int step = 0; step < budget; ++step) {
-        hipLaunchKernelGGL(k_stt_argmax, dim3(1), dim3(1024), 0, ctx->stream, s->logits, c.vocab, s->d_mask, step == 0 ? 1 : 0, s->d_tok);
-        RT_HIP(ctx, hipGetLastError());
-        int32_t tok = 0;
-        RT_HIP(ctx, hipMemcpyAsync(&tok, s->d_tok, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (tok == c.eos_id) break;
-        h_tokens[n++] = tok;
-        if (step + 1 < budget) ST_TRY(stt_decode_rows(s, 1, c.n_prefix + step));
+    for (int64_t off = 0; off == 0 || off < n_samples; off += win) {
+        if (n >= max_tokens) break;
+        const int64_t n_w = std::min<int64_t>(win, n_samples - off);
+        ST_TRY(stt_features(s, n_w > 0 ? d_pcm + off : d_pcm, n_w, sample_rate));
+        ST_TRY(stt_encode(s));
+        // forced prefix in one pass, then one token per pass: the host reads each token (end-of-sequence decides when to stop)
+        RT_HIP(ctx, hipMemcpyAsync(s->d_tok, c.prefix, c.n_prefix * 4, hipMemcpyHostToDevice, ctx->stream));
+        ST_TRY(stt_decode_rows(s, c.n_prefix, 0));
+        if (d_first_logits && off == 0) RT_HIP(ctx, hipMemcpyAsync(d_first_logits, s->logits, (size_t)c.vocab * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        const int budget = std::min(std::min(max_tokens - n, c.max_new_tokens), c.n_text_ctx - c.n_prefix);
+        for (int step = 0; step < budget; ++step) {
+            hipLaunchKernelGGL(k_stt_argmax, dim3(1), dim3(1024), 0, ctx->stream, s->logits, c.vocab, s->d_mask, step == 0 ? 1 : 0, s->d_tok);
+            RT_HIP(ctx, hipGetLastError());
+            int32_t tok = 0;
+            RT_HIP(ctx, hipMemcpyAsync(&tok, s->d_tok, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (tok == c.eos_id) break;
+            h_tokens[n++] = tok;
+            if (step + 1 < budget) ST_TRY(stt_decode_rows(s, 1, c.n_prefix + step));
+        }
     }
     *h_n_tokens = n;
     return RT_OK;

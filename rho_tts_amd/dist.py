@@ -183,6 +183,21 @@ def agree(dist, device, code: int) -> int:
     return int(t.item())
 
 
+def min_max(dist, device, value: int) -> Tuple[int, int]:
+    """(smallest, largest) of one integer per rank - a limit every rank must apply alike (take the min), a digest that must be
+    the same everywhere (min == max), the furthest stage any rank reached (max).  One two-word all-reduce."""
+    t = torch.tensor([-int(value), int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return -int(t[0].item()), int(t[1].item())
+
+
+def broadcast_ints(dist, device, values: Sequence[int], src: int = 0) -> List[int]:
+    """Rank ``src``'s integers on every rank (the seed a call starts from, the clock reading its retry seeds derive from)."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src)
+    return [int(v) for v in t.tolist()]
+
+
 def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     """One process per GPU under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment): initialise the process group - "nccl" IS RCCL on ROCm - BEFORE anything touches the GPU, and return

@@ -51,17 +51,47 @@ class BatchedPipeline:
 
     def _run_pipeline(self, texts, cancellation_token, progress_callback=None):
         plans = self._plan_texts(texts, cancellation_token)
+        self._begin_retry_seeds()
         return self._run_plans(plans, list(range(len(plans))), cancellation_token, progress_callback)
 
-    def _plan_texts(self, texts, token) -> List[List[str]]:
-        """Phonetic mapping, then segmentation per text with the memory-aware limit (base_tts.py:721,727-731)."""
+    def _plan_texts(self, texts, token, max_chars: Optional[int] = None) -> List[List[str]]:
+        """Phonetic mapping, then segmentation per text with the memory-aware limit (base_tts.py:721,727-731).
+        ``max_chars``: a limit agreed beforehand (data-parallel runs: every rank must cut the texts alike) instead of this
+        process's own free-memory reading."""
         mapped = [self._apply_phonetic_mapping(t) for t in texts]
         plans: List[List[str]] = []
         for idx, text in enumerate(mapped):
             if token.is_cancelled():
                 raise CancelledException(f"Cancelled during text item {idx}")
-            plans.append(self._split_text_into_segments(text, self._compute_max_chars()))
+            plans.append(self._split_text_into_segments(text, self._compute_max_chars() if max_chars is None else max_chars))
         return plans
+
+    # ---- retry seeds.  The reference reseeds from the wall clock at every decay retry and validation retry
+    # (``self.seed = int(time.time() * 1000) % 100000``, base_tts.py:743,778) and leaves ``self.seed`` mutated.  Here the clock is
+    # read ONCE per call and the seed of retry stage (decay attempt a, validation iteration k) is derived from that reading: still
+    # a fresh clock-dependent seed per retry, still left in ``self.seed`` - but a function of (clock reading, a, k) alone, so the
+    # ranks of a data-parallel call (which share rank 0's reading) give an item the audio one GPU would, retries included, and
+    # can agree afterwards on the seed the call leaves behind.
+    @staticmethod
+    def _retry_clock() -> int:
+        return int(time.time() * 1000) % 100000
+
+    def _begin_retry_seeds(self, base: Optional[int] = None, entry_seed: Optional[int] = None) -> None:
+        self._retry_base = int(self._retry_clock() if base is None else base)
+        self._entry_seed = int(self.seed if entry_seed is None else entry_seed)
+        self.seed = self._entry_seed
+        self._last_stage = (0, 0)
+
+    def _stage_seed(self, attempt: int, iteration: int) -> int:
+        if (attempt, iteration) == (0, 0):
+            return self._entry_seed
+        return int((self._retry_base + 7919 * attempt + 104729 * iteration) % 100000)
+
+    def _enter_stage(self, attempt: int, iteration: int) -> None:
+        if not hasattr(self, "_retry_base"):
+            self._begin_retry_seeds()
+        self.seed = self._stage_seed(attempt, iteration)
+        self._last_stage = max(getattr(self, "_last_stage", (0, 0)), (attempt, iteration))
 
     def _run_plans(self, plans, owned, token, progress_callback=None):
         """The pipeline for the text items ``owned`` (indices into ``plans``; all of them on one GPU, this rank's share in a
@@ -81,12 +111,12 @@ class BatchedPipeline:
             if not pending:
                 break
             if attempt > 0:
-                self.seed = int(time.time() * 1000) % 100000
+                self._enter_stage(attempt, 0)
                 logger.warning(f"  sound decay detected in {len(pending)} item(s), regenerating (attempt {attempt + 1}/{self.max_decay_retries})")
             work = [(i, s, seg) for i in pending for s, seg in enumerate(plans[i])]
             for i in pending:
                 seg_audio[i], scores[i] = [], ([], [])
-            got = self._generate_work(work, plans, token, progress_callback, scores, [seg_base[i] + s for i, s, _ in work])
+            got = self._generate_work(work, plans, token, progress_callback, scores, [seg_base[i] + s for i, s, _ in work], attempt)
             for (i, s, _), a in zip(work, got):
                 if a is not None:
                     seg_audio[i].append(a)
@@ -118,7 +148,7 @@ class BatchedPipeline:
         return out
 
     # one entry of `work` per (item, segment index, text); returns the accepted audio (or None) per entry
-    def _generate_work(self, work, plans, token, progress_callback, scores, stream_ids=None):
+    def _generate_work(self, work, plans, token, progress_callback, scores, stream_ids=None, attempt: int = 0):
         if stream_ids is None:
             stream_ids = list(range(len(work)))
         accepted: List[Optional[torch.Tensor]] = [None] * len(work)
@@ -131,7 +161,7 @@ class BatchedPipeline:
             if not todo:
                 break
             if iteration > 0:
-                self.seed = int(time.time() * 1000) % 100000
+                self._enter_stage(attempt, iteration)
             retry: List[int] = []
             for chunk in self._cut_batches(todo, work, bs):
                 for w in chunk:
@@ -235,17 +265,20 @@ class BatchedPipeline:
         auto-sort -> best-by-drift -> text match only if the voice passed.  A validator that raises counts as a failed
         attempt but keeps what it had already recorded.  Returns True when the attempt is accepted."""
         scorer, transcriber = getattr(self, "drift_scorer", None), getattr(self, "transcriber", None)
-        if scorer is None and not hasattr(self, "_validate_accent_drift"):
+        file_based = hasattr(self, "_validate_accent_drift")          # the reference's file-based validators (absent in the host mirror)
+        if scorer is None and transcriber is None and not file_based:
             st["best"] = audio
             return True
-        need_file = scorer is None or transcriber is None or bool(getattr(self, "auto_sort_good_dir", None) or getattr(self, "auto_sort_bad_dir", None))
+        need_file = file_based and (scorer is None or transcriber is None or bool(getattr(self, "auto_sort_good_dir", None) or getattr(self, "auto_sort_bad_dir", None)))
         try:
             with (self._validation_input(audio) if need_file else contextlib.nullcontext(None)) as path:
                 if scorer is not None:
                     drift = float(scorer(audio, self.sample_rate))
                     voice_ok = drift < self.accent_drift_threshold
-                else:
+                elif file_based:
                     drift, voice_ok = self._validate_accent_drift(path)
+                else:
+                    drift, voice_ok = 0.0, True                        # no classifier: passes, as base_tts.py:218-220 does
                 if path is not None and hasattr(self, "_auto_sort_audio"):
                     self._auto_sort_audio(path, drift)
                 if drift < st["best_drift"]:
@@ -255,9 +288,10 @@ class BatchedPipeline:
                     if transcriber is not None:
                         from .validation import validate_text_match
                         text_ok, sim, _ = validate_text_match(transcriber(audio, self.sample_rate), text, self.text_similarity_threshold)
-                    else:
+                        st["text_sim"] = sim
+                    elif file_based:
                         text_ok, sim, _ = self._validate_text_match(path, text)
-                    st["text_sim"] = sim
+                        st["text_sim"] = sim
                 if voice_ok and text_ok:
                     st["best"] = audio
                     return True
@@ -369,12 +403,33 @@ class DataParallelPipeline(BatchedPipeline):
         from . import dist as D
         td, rank, world = dp
         dev = self._dp_device(td)
-        plans, err = [], None
+        plans, err, mc = [], None, 0
+        # ---- what every rank must hold alike BEFORE anything is planned: the segment limit (it reads this process's free memory,
+        # base_tts.py:158-185, and is refined by the loaded checkpoint, qwen.py:131-139 - so the engine is loaded first and the
+        # ranks take the smallest limit any of them computed), the seed the call starts from and the clock reading its retry
+        # seeds derive from (rank 0's)
         try:
-            plans = self._plan_texts(texts, cancellation_token)        # the same on every rank
+            self._load_engine()
+            mc = int(self._compute_max_chars())
+        except BaseException as e:  # noqa: BLE001
+            err = e
+        self._dp_agree(td, dev, err, "loading")
+        mc, _ = D.min_max(td, dev, mc)
+        seed0, base0 = D.broadcast_ints(td, dev, [int(self.seed), self._retry_clock()], src=0)
+        self._begin_retry_seeds(base0, seed0)
+        try:
+            plans = self._plan_texts(texts, cancellation_token, max_chars=mc)
         except BaseException as e:  # noqa: BLE001  (a token cancelled on ONE rank: re-raised by _dp_agree, on every rank)
             err = e
         self._dp_agree(td, dev, err, "planning")
+        # the plans decide who owns what and where every waveform goes: a rank that cut its texts differently would drop or double
+        # items without any error - so the plans' digest must agree before the deal
+        import hashlib
+        digest = int.from_bytes(hashlib.sha256(repr(plans).encode("utf-8")).digest()[:7], "big")
+        lo, hi = D.min_max(td, dev, digest)
+        if lo != hi:
+            raise ValueError("data-parallel ranks planned different segmentations of the same texts (different texts, phonetic "
+                             "mappings or segment limits per rank): every rank must call generate() with the same arguments")
         self._dp_share_voice(td, rank, dev)
         shards = D.shard_items(self._dp_costs(plans), world)
         local = []
@@ -382,6 +437,11 @@ class DataParallelPipeline(BatchedPipeline):
             local = self._run_plans(plans, shards[rank], cancellation_token, progress_callback)
         except BaseException as e:  # noqa: BLE001  (re-raised by _dp_agree, on every rank)
             err = e
+        # the seed the call leaves in self.seed is the last retry stage ANY rank reached - what one process running every item
+        # would hold (its loops are attempt-major, iteration-minor) - so the next call starts alike on every rank
+        a_k = getattr(self, "_last_stage", (0, 0))
+        _, top = D.min_max(td, dev, a_k[0] * 100000 + a_k[1])
+        self.seed = self._stage_seed(top // 100000, top % 100000)
         self._dp_agree(td, dev, err, "generation")
         nan = float("nan")
         wavs = [None if r is None else r[0].reshape(-1) for r in local]
@@ -496,10 +556,14 @@ class MI355XQwenTTS(DataParallelPipeline, HipAudioLeaves, BaseTTS):
     def __init__(self, device: str = "cuda", seed: int = 789, deterministic: bool = False,
                  reference_audio: Optional[str] = None, reference_text: Optional[str] = None, speaker: Optional[str] = None,
                  language: str = "English", model_path: str = "Qwen/Qwen3-TTS-12Hz-1.7B-Base",
-                 max_chars_per_segment: Optional[int] = None, batch_size: int = 32, max_iterations: int = 1,
+                 max_chars_per_segment: Optional[int] = None, batch_size: int = 32, max_iterations: int = 10,
                  accent_drift_threshold: float = 0.17, text_similarity_threshold: float = 0.85,
                  sound_decay_threshold: float = 0.3, drift_model_path: Optional[str] = None,
                  phonetic_mapping: Optional[Dict[str, str]] = None):
+        # Defaults are QwenTTS.__init__'s (providers/qwen.py:48-66) with ONE deviation: batch_size 32 instead of 5.  The reference
+        # stores batch_size and never reads it (qwen.py:59,83), so no behaviour of its can depend on the value; here it is the
+        # number of decode rows (BASELINE.json's headline batch).  max_iterations keeps the reference's 10: a caller who swaps
+        # providers keeps the validation retries (they run whenever validators are installed or the tensor-level hooks are set).
         super().__init__(device, seed, deterministic, phonetic_mapping=phonetic_mapping)
         if reference_audio is not None and reference_text is None:
             raise ValueError("reference_text (transcript of reference audio) is required when reference_audio is set")

@@ -1,5 +1,5 @@
-"""CPU checks of the C-ABI boundary: the library builds, loads, and exports every
-symbol include/rho_tts_amd.h declares.  No compute call is made (no GPU here)."""
+"""CPU checks of the C-ABI boundary: the library builds, loads, and exports every symbol include/rho_tts_amd.h (the drop-in
+boundary) and include/rho_tts_amd_debug.h (measurement / test entry points) declare.  No compute call is made (no GPU here)."""
 import ctypes
 import os
 import re
@@ -9,27 +9,39 @@ from rho_tts_amd import _build, _native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "rho_tts_amd.h")).read()
+def declared_symbols(header="rho_tts_amd.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"RT_API\s+[^;(]*?\b(rt_\w+)\s*\(", src)))
 
 
 def test_header_declares_something():
     syms = declared_symbols()
-    assert "rt_create" in syms and "rt_post_process" in syms and len(syms) >= 10
+    assert "rt_create" in syms and "rt_post_process" in syms and "rt_generate" in syms and len(syms) >= 10
+
+
+def test_boundary_header_carries_no_measurement_or_test_entry_points():
+    """a host binding of the generation path sees no rt_debug_* / rt_bench_* / rt_profile_* declaration and no
+    tune-code table; those live in their own header, which includes the boundary."""
+    pub, dbg = declared_symbols(), declared_symbols("rho_tts_amd_debug.h")
+    assert not [s for s in pub if s.startswith(("rt_debug_", "rt_bench_", "rt_profile_"))]
+    assert dbg and all(s.startswith(("rt_debug_", "rt_bench_", "rt_profile_")) for s in dbg), dbg
+    assert not set(pub) & set(dbg)
+    assert "rt_debug_tune" not in open(os.path.join(ROOT, "include", "rho_tts_amd.h")).read()
+    assert '#include "rho_tts_amd.h"' in open(os.path.join(ROOT, "include", "rho_tts_amd_debug.h")).read()
 
 
 def test_library_builds_and_exports_every_declared_symbol():
     path = _build.build_native()
     lib = ctypes.CDLL(path)
-    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
-    assert not missing, f"declared in the header but not exported: {missing}"
+    for header in _build.PUBLIC_HEADERS:
+        missing = [s for s in declared_symbols(header) if not hasattr(lib, s)]
+        assert not missing, f"declared in {header} but not exported: {missing}"
 
 
 def test_abi_version_and_status_strings():
     lib = _native.load_library()
-    assert lib.rt_abi_version() == 5
+    assert lib.rt_abi_version() == 6
     assert lib.rt_status_string(0) == b"ok"
     assert b"memory" in lib.rt_status_string(_native.RT_ERR_OOM)
 

@@ -182,7 +182,7 @@ def _dp_provider_class():
     class _Engine:
         def __init__(self, rank):
             self.device, self.model, self.voice, self.cfg, self.tokenizer = torch.device("cpu"), _FakeModel(rank), None, _Cfg(), _Tok()
-            self.encoded, self.calls, self.fail_on = 0, [], set()
+            self.encoded, self.calls, self.fail_on, self.decay_on, self.seeds = 0, [], set(), set(), []
 
         def frames_for(self, text, n_tokens):
             return 4 * max(1, len(text.split()))
@@ -204,7 +204,11 @@ def _dp_provider_class():
                 env = np.ones(n)
                 env[:1500] = 0.0
                 env[-1500:] = 0.0
-                out.append(torch.from_numpy(((0.25 * np.sin(2 * np.pi * (180.0 + 7.0 * (len(t) % 40)) * k / 24000) + 1e-3 * (i + 1)) * env).astype(np.float32)))
+                if t in self.decay_on and seed == 789:                 # decays with the seed the call started from: one regeneration
+                    env *= np.linspace(1.0, 0.02, n)
+                self.seeds.append(int(seed))
+                tone = 0.25 * np.sin(2 * np.pi * (180.0 + 7.0 * (len(t) % 40) + 0.5 * (int(seed) % 89)) * k / 24000)   # the seed is audible
+                out.append(torch.from_numpy(((tone + 1e-3 * (i + 1)) * env).astype(np.float32)))
             if stats is not None:
                 stats["batches"] = stats.get("batches", 0) + 1
             return out
@@ -356,3 +360,91 @@ def test_pick_rows_cost_model():
     assert pick_rows(ragged, 64) == 32                                 # measured: 423 against 396 audio-s/s
     assert pick_rows(ragged * 8, 64) == 64                             # a long queue keeps 64 rows busy
     assert pick_rows(ragged, 32) == 32 and pick_rows(ragged[:33], 64) in (32, 33)
+
+
+def _dp_retry_worker(rank, world, port, q):
+    """VERDICT r3 #7 / ADVICE r3: a decay retry on ONE rank must leave every rank with the seed one process would hold, so that the
+    NEXT generate() gives a text the same audio whatever the number of ranks; ranks that would cut the texts differently (another
+    segment limit) take the smallest limit, and ranks called with different texts fail loudly instead of misplacing waveforms."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["RHO_TTS_AMD_SYNTHETIC"] = "1"
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    from rho_tts_amd import api
+    cls = _dp_provider_class()
+    cls._retry_clock = staticmethod(lambda: 4242)              # the wall clock of the retry seeds, frozen for the comparison
+    texts = list(_DP_TEXTS[:3]) + ["This text decays at the first try", "Five", "Six is the last one here"]
+
+    def make():
+        t = cls(device="cuda", reference_audio="ref.wav", reference_text="the reference words", batch_size=4)
+        t._max_chars_explicit = True
+        t.force_sentence_split = True
+        eng = t._load_engine()
+        eng.decay_on = {"This text decays at the first try"}
+        return t, eng
+
+    solo, solo_eng = make()
+    want1 = _dp_record(solo._run_pipeline(list(texts), api.CancellationToken(), None))
+    seed_after = solo.seed
+    want2 = _dp_record(solo._run_pipeline(list(texts), api.CancellationToken(), None))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, why = True, ""
+
+    def check(cond, msg):
+        nonlocal ok, why
+        if not cond and ok:
+            ok, why = False, msg
+    try:
+        from rho_tts_amd import dist as D
+        check(seed_after == solo._stage_seed(1, 0) != 789 and 789 in solo_eng.seeds and seed_after in solo_eng.seeds, f"solo seeds {solo_eng.seeds}")
+        t, eng = make()
+        if rank == 1:
+            t.seed = 31337                                       # a rank that starts from another seed takes rank 0's
+        got1 = _dp_record(t._run_pipeline(list(texts), api.CancellationToken(), None))
+        plans = t._plan_texts(list(texts), api.CancellationToken())
+        shards = D.shard_items(t._dp_costs(plans), world)
+        owner = [r for r in range(world) if 3 in shards[r]][0]
+        retried = len(set(eng.seeds)) > 1
+        check(retried == (rank == owner), f"rank {rank}: retry seeds {sorted(set(eng.seeds))}, owner of the decaying text {owner}")
+        check(t.seed == seed_after, f"rank {rank} left seed {t.seed}, one process leaves {seed_after}")
+        got2 = _dp_record(t._run_pipeline(list(texts), api.CancellationToken(), None))
+        if rank == 0:
+            check(got1 == want1, f"first call differs from one GPU: {got1} vs {want1}")
+            check(got2 == want2, f"the call AFTER a retry differs from one GPU: {got2} vs {want2}")
+            check(want2 != want1, "the second call should start from the retry's seed")
+        else:
+            check(all((got2[i] == want2[i]) if i in shards[rank] else got2[i] is None for i in range(len(want2))), f"worker second call {got2}")
+        # ranks whose own segment limit differs cut the texts at the SMALLEST one
+        long_text = " ".join(f"Sentence number {k} of a long paragraph." for k in range(40))
+        t.force_sentence_split = False
+        t.max_chars_per_segment = 400 if rank == 0 else 900
+        res = t._run_pipeline([long_text, "Short"], api.CancellationToken(), None)
+        if rank == 0:
+            check(res[0] is not None and res[0][1] == len(t._split_text_into_segments(long_text, 400)), f"segments {res[0] and res[0][1]}")
+        # different texts on the ranks: refused on every rank, nothing misplaced
+        try:
+            t._run_pipeline(["Same first text", "rank %d says something else" % rank], api.CancellationToken(), None)
+            check(False, "diverging plans were not refused")
+        except ValueError as e:
+            check("planned different segmentations" in str(e), str(e))
+        q.put((rank, ok, why))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_provider_data_parallel_retry_seeds_and_plan_agreement_gloo():
+    _FakeModel.n_imports = 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_retry_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

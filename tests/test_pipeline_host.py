@@ -258,7 +258,9 @@ def test_provider_constructor_contract_without_gpu():
     with pytest.raises(ValueError):
         MI355XQwenTTS(device="cpu")                                     # no CPU path, said loudly
     p = MI355XQwenTTS(speaker="Ryan", model_path="Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice")
-    assert p.sample_rate == 24000 and p.batch_size == 32 and p.force_sentence_split is False and p.max_iterations == 1
+    # defaults = QwenTTS.__init__'s (providers/qwen.py:59-60) except batch_size (dead configuration there, the decode rows here)
+    assert p.sample_rate == 24000 and p.batch_size == 32 and p.force_sentence_split is False and p.max_iterations == 10
+    assert (p.accent_drift_threshold, p.text_similarity_threshold, p.sound_decay_threshold, p.seed) == (0.17, 0.85, 0.3, 789)
     assert p.voice_cloning is False and p.provider_info().supports_voice_cloning
     from rho_tts_amd import api
     saved = dict(api.TTSFactory._providers)
