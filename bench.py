@@ -132,7 +132,9 @@ def main():
     ap.add_argument("--ref-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: probe 16/32/64/128/all host cores and take the fastest)")
+    ap.add_argument("--phase-times", action="store_true", help="wait for the GPU after every phase of a step and report the wall ms per phase in extra.phase_ms "
+                    "(a diagnostic: the waits cost a little throughput)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: probe 8, 16, 32, ... host cores in ascending order while more threads still pay, take the fastest)")
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--corpus", type=int, default=0, help="C4: one corpus of this many ragged texts for the whole job (strong scaling)")
@@ -227,23 +229,40 @@ def main():
 
     sched = {}                                                # kept / launched row-frames of the decode schedule (this rank, all steps)
 
+    phases = {}                                                # --phase-times: wall ms per phase of the timed steps on this rank (synchronising)
+
+    def mark(name, t_prev):
+        if not args.phase_times:
+            return t_prev
+        torch.cuda.synchronize()
+        eng.ctx.synchronize()
+        now = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + (now - t_prev) * 1e3
+        return now
+
     def step():
+        tp = time.perf_counter()
         if dist is None or rank == 0:
             # conditioning, once per step as the reference does per call (ref_audio=path, qwen.py:253-258): the 30-s clip through
             # the audio encoder (codes + speaker embedding) and the voice prefix through the talker (its K/V)
             eng.set_voice_from_audio(clip, ref_text)
+        tp = mark("conditioning", tp)
         if dist is not None:
             broadcast_voice(eng, dist, src=0, comm_device=comm_dev)
+        tp = mark("voice broadcast", tp)
         raw = eng.synthesize(texts, seed=789, item_ids=item_ids, max_frames=my_frames, plan_frames=my_plan, stats=sched,
                              continuous=False if args.static_batches else None) if texts else []
+        tp = mark("decode + codec decoder", tp)
         outs, stats = eng.post_process([[w] for w in raw], post) if raw else ([], [])
+        tp = mark("post-processing", tp)
         audio_s = sum(o.numel() for o in outs) / cfg.sample_rate   # delivered (post-processed) samples
         if dist is not None:
-            host = gather_waveforms(outs, dist, dst=0, device=comm_dev)
+            host = gather_waveforms(outs, dist, dst=0, device=comm_dev, copy=False)   # (views of pinned staging, read before the step after next)
             if corpus is not None and rank == 0:
                 host = unshard(host, shards, len(corpus))
         else:
-            host = waveforms_to_host(outs)
+            host = waveforms_to_host(outs, copy=False)
+        tp = mark("waveforms to rank 0 / host", tp)
         return audio_s, host
 
     log(f"engine ready: {eng.model.weight_bytes() / 1e9:.2f} GB of weights; warmup x{args.warmup}")
@@ -259,6 +278,7 @@ def main():
 
     sync()
     sched.clear()
+    phases.clear()
     t0 = time.perf_counter()
     audio_local = 0.0
     for _ in range(args.steps):
@@ -269,6 +289,7 @@ def main():
         assert len(_host) == len(corpus) and all(w is not None and w.numel() > 0 for w in _host), "corpus: a waveform is missing"
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
+    phase_ms = {k: round(v / max(1, args.steps), 3) for k, v in phases.items()} if args.phase_times else None
     t = torch.tensor([dt, audio_local], dtype=torch.float64, device=comm_dev)
     if dist is not None:
         tmax = t.clone()
@@ -372,6 +393,8 @@ def main():
                                    "audio_s_per_s_at_roofline": round(B * 0.08 / (extra["bytes_per_frame"] / 8.0e12), 1)}
         if roof is not None and extra_families:
             extra["kernel_families"] = extra_families
+    if phase_ms is not None:
+        extra["phase_ms"] = phase_ms
     if corpus is not None:
         extra.update({"corpus_texts": len(corpus), "corpus_frames": int(sum(actual)), "length_error": args.length_error,
                       # rows kept busy by the decode schedule of rank 0, measured (kept frames / (frames launched x rows));
@@ -474,7 +497,8 @@ def cpu_baseline(cfg, args, eng):
     # 32-row GEMMs - so it is MEASURED here, not assumed: 2 decode frames of the workload's batch behind a 4-frame voice prefix
     # at each candidate, and the sample below runs with the fastest (the probe's seconds per frame are reported in `thread_probe`).
     probe = {}
-    cands = sorted({c for c in (16, 32, 64, 128, host_cores) if c <= host_cores} | {min(host_cores, 32)})
+    cands = [c for c in (8, 16, 32, 64, 128, host_cores) if c <= host_cores]
+    cands = sorted(set(cands))
     if args.cpu_threads > 0:
         cands = [min(args.cpu_threads, host_cores)]
     if len(cands) > 1:
@@ -482,6 +506,11 @@ def cpu_baseline(cfg, args, eng):
         pv = Voice("english", None, torch.zeros(H_), [3, 4, 5], torch.zeros(4, cfg.n_groups, dtype=torch.int64))
         p_ids = [eng.tokenizer.encode(t) for t in sentences(B, args.words, seed=789)]
         for c in cands:
+            # ascending, and stop once a count is clearly slower than the best so far: eager PyTorch gets SLOWER with more threads on
+            # these 32-row GEMMs (first measurement on a 256-core host: 0.38 / 0.63 / 1.55 / 4.2 s per frame at 16 / 32 / 64 / 128
+            # threads; at 256 the probe alone ran for minutes), so the large counts are only tried while they still pay
+            if probe and min(probe.values()) * 1.5 < probe[max(probe)]:
+                break
             torch.set_num_threads(c)
             tmp = {}
             with torch.no_grad():

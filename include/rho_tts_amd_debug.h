@@ -95,7 +95,8 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   2100/2101 the codec decoder's 96-channel residual units as two launches (k = 7 conv, 1x1 conv) / one fused launch |
  *   2200/2201 prompt-prefill attention behind a shared voice prefix on the vector unit / on the matrix cores |
  *   2300/2301 decode GEMMs of <= 16 rows on the 32-row / the two-workgroups-per-CU 16-row instantiation |
- *   2400/2401 gate/up decode GEMM whose tile pairs are 1.5x the CUs: one pair per workgroup (1.5 rounds) / 1.5 pairs per workgroup (one round)
+ *   2400/2401 gate/up decode GEMM whose tile pairs are 1.5x the CUs: one pair per workgroup (1.5 rounds) / 1.5 pairs per workgroup (one round) |
+ *   2500/2501 the decode frame counter advanced by a launch of its own / by the talker step's last GEMM launch
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);
@@ -105,6 +106,11 @@ RT_API int rt_bench_launch(rt_ctx* ctx, int32_t grid_wgs, int32_t n, int32_t use
 RT_API int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, int32_t mode, double* us_per_barrier, int32_t* aborted);
 RT_API int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, const rt_sampling* sp, int32_t iters, double* avg_us,
                            int64_t* stamps8);
+/* iters back-to-back launches of the decode step's fused attention: M rows at position prefix_len + own_len - 1, the first
+ * prefix_len positions read from a shared prefix slot (shared = 1) or from each row's own slot (0), cycling through `layers`
+ * cache regions; zeros as operands. */
+RT_API int rt_bench_attention_fused(rt_ctx* ctx, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t prefix_len, int32_t own_len,
+                                    int32_t shared, int32_t layers, int32_t iters, double* avg_us);
 RT_API int rt_bench_gemm_skinny(rt_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t split_k, int32_t n_mats, int32_t iters,
                                 double* avg_us, int32_t* used_split);
 

@@ -303,6 +303,7 @@ int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
     // flight keeps the plan it began with - the switch is refused rather than applied under it
     std::unique_lock<std::shared_mutex> all(g_tune_mu);
     if (g_runs_in_flight.load() > 0) return RT_ERR_STATE;
+    if (skinny_variant >= 2500) { g_fold_frame_inc = skinny_variant - 2500; return RT_OK; }        // 2500/2501: frame counter advanced by k_frame_inc / by the talker step's last GEMM launch
     if (skinny_variant >= 2400) { g_col_silu_x = skinny_variant - 2400; return RT_OK; }            // 2400/2401: gate/up decode GEMM as pairs in 1.5 rounds / as one round of 1.5-pair workgroups
     if (skinny_variant >= 2300) { g_col_rows16 = skinny_variant - 2300; return RT_OK; }           // 2300/2301: <= 16-row decode GEMMs on the 32-row / the 2-workgroups-per-CU 16-row instantiation
     if (skinny_variant >= 2200) { g_prefill_attn_mfma = skinny_variant - 2200; return RT_OK; }    // 2200/2201: prompt attention behind a shared prefix on the vector unit / matrix cores
@@ -506,6 +507,66 @@ int rt_bench_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_t V, co
     if (stamps8) RT_HIP(ctx, hipMemcpy(stamps8, st, 64, hipMemcpyDeviceToHost));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(items); (void)hipFree(out); (void)hipFree(st);
+    return rc;
+}
+
+// Decode-attention microbenchmark: `iters` back-to-back launches of the decode step's fused attention over M rows, each row at
+// position prefix_len + own_len - 1 of its own slot, positions < prefix_len read from a shared prefix slot (shared != 0) or from
+// the row's own slot (shared == 0: what the launch would cost without the shared voice prefix).  The launches cycle through
+// `layers` cache regions (as the model's 28 layers do: a layer's K / V is L2-cold when its turn comes).  Operands are zeros
+// (uniform softmax): the timing does not depend on the values.
+int rt_bench_attention_fused(rt_ctx* ctx, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim, int32_t prefix_len, int32_t own_len,
+                             int32_t shared, int32_t layers, int32_t iters, double* avg_us) {
+    if (!ctx || !avg_us || M < 1 || M > 64 || heads < 1 || kv_heads < 1 || heads % kv_heads || prefix_len < 0 || own_len < 1 || layers < 1 || iters < 1)
+        return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_attention_fused: bad argument");
+    CtxLock g(ctx);
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    // (more than 64 cache rows select the 16-wave form of the talker's decode step; the predictor's <= 16 positions the 4-wave form)
+    const int max_pos = std::max((prefix_len + own_len + 8 + 63) / 64 * 64, (prefix_len > 0 || own_len > 16) ? 128 : 64), slots = M + 1, width = (heads + 2 * kv_heads) * head_dim;
+    KvCache kv;
+    kv.layers = layers; kv.slots = slots; kv.kv_heads = kv_heads; kv.max_pos = max_pos; kv.head_dim = head_dim;
+    kv.prefix_slot = shared && prefix_len > 0 ? M : -1;
+    kv.prefix_len = kv.prefix_slot >= 0 ? prefix_len : 0;
+    const size_t cache_bytes = (size_t)layers * kv.layer_stride() * sizeof(bf16_t);
+    float *qkv = nullptr, *cs = nullptr, *nw = nullptr;
+    int32_t *pos = nullptr, *slot = nullptr;
+    bf16_t* out = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&kv.k, cache_bytes));
+    RT_HIP(ctx, hipMalloc((void**)&kv.v, cache_bytes));
+    RT_HIP(ctx, hipMalloc((void**)&qkv, (size_t)M * width * 4));
+    RT_HIP(ctx, hipMalloc((void**)&cs, (size_t)max_pos * head_dim * 4));
+    RT_HIP(ctx, hipMalloc((void**)&nw, (size_t)head_dim * 4));
+    RT_HIP(ctx, hipMalloc((void**)&pos, (size_t)M * 4));
+    RT_HIP(ctx, hipMalloc((void**)&slot, (size_t)M * 4));
+    RT_HIP(ctx, hipMalloc((void**)&out, ((size_t)M + 31) / 32 * 32 * heads * head_dim * 2));
+    RT_HIP(ctx, hipMemsetAsync(kv.k, 0, cache_bytes, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(kv.v, 0, cache_bytes, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(qkv, 0, (size_t)M * width * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(cs, 0, (size_t)max_pos * head_dim * 4, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(nw, 0, (size_t)head_dim * 4, ctx->stream));
+    std::vector<int32_t> hp(M, prefix_len + own_len - 1), hs(M);
+    for (int i = 0; i < M; ++i) hs[i] = i;
+    RT_HIP(ctx, hipMemcpyAsync(pos, hp.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(slot, hs.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    const float* cosT = cs;
+    const float* sinT = cs + (size_t)max_pos * head_dim / 2;
+    int rc = RT_OK;
+    for (int i = 0; i < layers && rc == RT_OK; ++i)          // warm-up: one pass over every layer
+        rc = launch_attention_fused(ctx, qkv, M, heads, kv_heads, head_dim, nw, nw, 1e-6f, cosT, sinT, slot, pos, 0, 0, kv, i, out, nullptr, 1, -1);
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < iters && rc == RT_OK; ++i)
+        rc = launch_attention_fused(ctx, qkv, M, heads, kv_heads, head_dim, nw, nw, 1e-6f, cosT, sinT, slot, pos, 0, 0, kv, i % layers, out, nullptr, 1, -1);
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (void* p : {(void*)kv.k, (void*)kv.v, (void*)qkv, (void*)cs, (void*)nw, (void*)pos, (void*)slot, (void*)out}) (void)hipFree(p);
     return rc;
 }
 

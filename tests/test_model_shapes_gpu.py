@@ -236,3 +236,174 @@ def test_batch_invariance_and_64_rows_at_the_0p6b_shape(ctx):
             assert torch.equal(wide[i], nm.generate([short[i]], [fr[i]], sp, seed=6, item_ids=[i])[0]), i
     finally:
         nm.close()
+
+
+def test_whole_sequence_at_c3_teacher_forced_and_free_running(ctx):
+    """the bench shape END TO END in time - 1.7B, 32 rows on the GPU, 460-row clone prefix, all 44 frames (positions
+    473 .. 517: RoPE far behind the prefix, repetition history filling up).  The oracle runs the first 8 items (its cost, not the
+    GPU's, sets the slice); the GPU decodes all 32 rows teacher-forced on the oracle's greedy trajectory.  Checked: the
+    self-calibrated logit bound at frames 0, 22 and 43 and over all frames; per frame, the share of codes whose GPU argmax under
+    teacher forcing is the oracle's code; and the FREE-running greedy decode against the oracle's (compounding: one differing
+    code changes everything behind it - reported as a curve, asserted where a floor exists: the first two frames)."""
+    from rho_tts_amd._native_model import NativeModel, RtSampling
+    from rho_tts_amd.tokenizer import HashTokenizer
+    cfg = config.PRESETS["1.7b"]()
+    B, NO, T = 32, 8, 44
+    tok = HashTokenizer(cfg.text_vocab)
+    state = weights.synthetic_state(cfg, 789, device="cuda")
+    nm = NativeModel(ctx, cfg, max_batch=B)
+    try:
+        nm.load_state(state)
+        cpu_state = {k: v.cpu() for k, v in state.items()}
+        om, om32 = OracleModel(cfg, cpu_state, act_bf16=True), OracleModel(cfg, cpu_state)
+        del state
+        torch.cuda.empty_cache()
+        cond = clone_voice(cfg, tok)
+        v = Voice(cond.language, None, cond.speaker_embed, cond.ref_text_ids, cond.ref_codes)
+        assert nm.set_voice(v.language, None, v.speaker_embed, v.ref_text_ids, v.ref_codes) == 460
+        texts = [tok.encode(t) for t in sentences(B, 10, 789)]
+        tr_o, tr_32 = {}, {}
+        with torch.no_grad():
+            free = om.generate(v, texts[:NO], [T] * NO, SamplingParams(), trace=tr_o, share_prefix=True)
+            om32.generate(v, texts[:NO], [T] * NO, SamplingParams(), trace=tr_32, share_prefix=True, forced_codes=free)
+        forced = list(free) + [free[b % NO] for b in range(NO, B)]          # rows 8..31 ride along (rows never see each other)
+        greedy = RtSampling(0, 1.0, 1, 1.0, 1.0)
+        codes, tr = nm.generate(texts, [T] * B, greedy, forced_codes=forced, trace=True)
+        assert all(torch.equal(a, b) for a, b in zip(codes, forced))
+        V0, G1 = cfg.codec.codebook_size, cfg.n_groups - 1
+        t16, t32 = torch.stack(tr_o["talker_logits"])[..., :V0], torch.stack(tr_32["talker_logits"])[..., :V0]          # [T, NO, V0]
+        p16 = torch.stack(tr_o["pred_logits"]).view(T, G1, NO, -1)
+        p32 = torch.stack(tr_32["pred_logits"]).view(T, G1, NO, -1)
+        tg = tr["talker"][:T, :NO, :V0].cpu()
+        pg = tr["predictor"][:T, :, :NO].cpu()
+
+        def dist(x, y, sig):
+            e = (x - y).abs()
+            return float(e.pow(2).mean().sqrt()) / sig, float(e.max()) / sig
+
+        for name, o16, o32, gpu in (("talker", t16, t32, tg), ("predictor", p16, p32, pg)):
+            sig = float(o16.std())
+            for label, sl in (("frame 0", slice(0, 1)), ("frame 22", slice(22, 23)), ("frame 43", slice(43, 44)), ("all 44 frames", slice(0, T))):
+                floor_rms, floor_max = dist(o16[sl], o32[sl], sig)
+                rms, mx = dist(gpu[sl], o16[sl], sig)
+                print(f"\n1.7B B=32 {name} {label}: GPU vs bf16 oracle rms {rms:.5f} max {mx:.5f} sigma; bf16 vs f32 oracle rms {floor_rms:.5f} max {floor_max:.5f}")
+                assert rms <= RMS_SLACK * floor_rms and rms <= RMS_CAP, (name, label, rms, floor_rms)
+                assert mx <= MAX_SLACK * floor_max and mx <= MAX_CAP, (name, label, mx, floor_max)
+            assert abs(float((gpu - o16).mean())) / sig < 2e-4
+        # teacher-forced choice agreement per frame: GPU argmax == the oracle's code (group 0 over the codebook ids, groups 1..15)
+        want = torch.stack(list(free))                                          # [NO, T, G]
+        a0 = (tg.argmax(-1).T == want[:, :, 0]).float()                         # [NO, T]
+        ag = (pg.argmax(-1).permute(2, 0, 1) == want[:, :, 1:]).float()         # [NO, T, G1]
+        tf_curve = ((a0 + ag.sum(-1)) / cfg.n_groups).mean(0)                   # per frame
+        print("\nteacher-forced argmax agreement per frame:", " ".join(f"{float(x):.3f}" for x in tf_curve))
+        assert float(tf_curve.min()) >= 0.93 and float(tf_curve[[0, 22, 43]].min()) >= 0.93, tf_curve
+        # free-running greedy decode of the same 32 rows against the oracle's own trajectory
+        got = nm.generate(texts, [T] * B, greedy)
+        eq = torch.stack([(got[b] == free[b]).float().mean(-1) for b in range(NO)])          # [NO, T] share of the 16 codes
+        curve = eq.mean(0)
+        print("free-running code agreement per frame:", " ".join(f"{float(x):.3f}" for x in curve))
+        # Measured on MI355X: 1.000 0.938 0.703 0.320 0.258 0.203 0.188 0.117 0.04 ... 0.0 at frame 43.  Greedy decoding of SEEDED
+        # weights is chaotic - the logits of a frame are nearly flat, 2-5 % of the argmax choices sit inside the bf16 noise (the
+        # teacher-forced curve above), and one differing code changes every later frame - so two correct bf16 implementations part
+        # within a few frames and the free-running curve has no floor to assert at frame 43 (it is 0 there for ANY pair, the bf16
+        # and float32 oracles included).  What holds at every frame is the teacher-forced agreement; free-running, only the start.
+        assert float(curve[0]) >= 0.9 and float(curve[1]) >= 0.75, curve
+    finally:
+        nm.close()
+
+
+def test_c2_through_the_provider_end_to_end(ctx, tmp_path, monkeypatch):
+    """BASELINE.json configs[1] driven the way a user drives it: ``MI355XQwenTTS(model_path=...0.6B-Base, batch_size=8).generate()``
+    with a 30-s reference WAV on disk and validation off (max_iterations = 1), sampled decoding.  Two of the eight delivered
+    waveforms are rebuilt on the CPU from the codes the GPU chose - oracle code2wav -> oracle post-processing - and must agree to
+    RMSE < 1e-3 END TO END (provider, engine, decode, codec decoder, fused post-processing, hand-over); the oracle, teacher-forced
+    on those codes, must make the same draws (same uniforms: oracle/sampling.py) at all but the few frames where the bf16 logit
+    distance moves a boundary of the inverse CDF."""
+    import wave
+
+    import numpy as np
+
+    from oracle import postprocess as OP
+    from oracle.sampling import draw, uniform
+    from rho_tts_amd.provider import MI355XQwenTTS
+    from rho_tts_amd.voice import synthetic_reference_clip
+    monkeypatch.setenv("RHO_TTS_AMD_SYNTHETIC", "1")
+    cfg = config.PRESETS["0.6b"]()
+    clip = synthetic_reference_clip(30.0, cfg.sample_rate, 789)
+    ref = str(tmp_path / "ref.wav")
+    with wave.open(ref, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(cfg.sample_rate)
+        wf.writeframes((np.clip(clip, -1, 1) * 32767).astype("<i2").tobytes())
+    ref_text = " ".join(WORDS[i % len(WORDS)] for i in range(75))
+    texts = sentences(8, 10, 4242)
+    t = MI355XQwenTTS(device="cuda", reference_audio=ref, reference_text=ref_text, model_path="Qwen/Qwen3-TTS-12Hz-0.6B-Base",
+                      batch_size=8, max_iterations=1)
+    try:
+        res = t.generate(texts)
+        assert res is not None and len(res) == 8 and all(r is not None and r.audio.numel() > 24000 for r in res)
+        eng = t._load_engine()
+        assert eng.cfg.name == cfg.name and eng.model.prefix_len() == 460
+        codes = eng.generate_codes(texts, seed=int(t.seed), item_ids=list(range(8)))       # the codes that call decoded (same seed, same streams)
+        state = {k: v.cpu() for k, v in weights.synthetic_state(cfg, 789, device="cuda").items()}
+        om = OracleModel(cfg, state, act_bf16=True)
+        del state
+        Q = cfg.codec.num_quantizers
+        post = OP.PostParams(sample_rate=cfg.sample_rate)
+        for b in (0, 5):
+            with torch.no_grad():
+                wav = om.code2wav(codes[b][:, :Q].T[None])[0]
+            y, ratio, ok = OP.finish_item([wav], post)
+            got = res[b].audio.reshape(-1).cpu()
+            assert got.numel() == y.numel(), (got.numel(), y.numel())
+            rmse = float(torch.sqrt(torch.mean((got - y.reshape(-1)) ** 2)))
+            print(f"\nC2 item {b}: delivered waveform vs oracle rebuilt from the GPU's codes: RMSE {rmse:.2e} over {got.numel()} samples, decay {ratio:.3f}")
+            assert rmse < 1e-3, rmse
+            assert abs(res[b].decay_ratio - ratio) < 1e-4 * max(1.0, ratio)
+        # the oracle, teacher-forced on the GPU's codes, draws with the same uniforms: how often does it pick the GPU's code?
+        v = Voice(eng.voice.language, None, eng.voice.speaker_embed, eng.voice.ref_text_ids, eng.voice.ref_codes)
+        ids = [eng.tokenizer.encode(x) for x in (texts[0], texts[5])]
+        fc = [codes[0], codes[5]]
+        tr = {}
+        sp_t, sp_p = eng.params.talker(), eng.params.predictor()
+        from oracle.sampling import SamplingParams as SP
+        st = SP(bool(sp_t.do_sample), sp_t.temperature, sp_t.top_k, sp_t.top_p, sp_t.repetition_penalty)
+        spd = SP(bool(sp_p.do_sample), sp_p.temperature, sp_p.top_k, sp_p.top_p, sp_p.repetition_penalty)
+        with torch.no_grad():
+            om.generate(v, ids, [c.shape[0] for c in fc], st, spd, seed=int(t.seed), item_ids=[0, 5], forced_codes=fc, trace=tr, share_prefix=True)
+        T = fc[0].shape[0]
+        tl = torch.stack(tr["talker_logits"])                                    # [T, 2, V]
+        pl = torch.stack(tr["pred_logits"]).view(T, cfg.n_groups - 1, 2, -1)
+        hit = tot = 0
+        for k, item in enumerate((0, 5)):
+            seen = np.zeros(cfg.codec_vocab, dtype=bool)
+            for f in range(T):
+                c0 = draw(tl[f, k].numpy(), st, uniform(int(t.seed), item, f, 0), om.talker_suppress(False), seen)
+                hit += int(c0 == int(fc[k][f, 0])); tot += 1
+                seen[int(fc[k][f, 0])] = True
+                for g in range(cfg.n_groups - 1):
+                    cg = draw(pl[f, g, k].numpy(), spd, uniform(int(t.seed), item, f, g + 1))
+                    hit += int(cg == int(fc[k][f, g + 1])); tot += 1
+        print(f"oracle draws equal to the GPU's sampled codes under teacher forcing: {hit}/{tot} = {hit / tot:.4f}")
+        # How often can two correct implementations agree on a DRAW?  The candidates are ordered by logit, the seeded weights give
+        # nearly flat logits, and a 0.7 %-sigma perturbation swaps neighbours in that order: the float32 oracle, teacher-forced on
+        # the same codes with the same uniforms, is the yardstick (measured: GPU vs bf16 oracle 0.81).
+        om32 = OracleModel(cfg, {k: v.cpu() for k, v in weights.synthetic_state(cfg, 789, device="cuda").items()})
+        tr32 = {}
+        with torch.no_grad():
+            om32.generate(v, ids, [c.shape[0] for c in fc], st, spd, seed=int(t.seed), item_ids=[0, 5], forced_codes=fc, trace=tr32, share_prefix=True)
+        tl32 = torch.stack(tr32["talker_logits"])
+        pl32 = torch.stack(tr32["pred_logits"]).view(T, cfg.n_groups - 1, 2, -1)
+        same = 0
+        for k, item in enumerate((0, 5)):
+            seen = np.zeros(cfg.codec_vocab, dtype=bool)
+            for f in range(T):
+                u0 = uniform(int(t.seed), item, f, 0)
+                same += int(draw(tl[f, k].numpy(), st, u0, om.talker_suppress(False), seen) == draw(tl32[f, k].numpy(), st, u0, om.talker_suppress(False), seen))
+                seen[int(fc[k][f, 0])] = True
+                for g in range(cfg.n_groups - 1):
+                    ug = uniform(int(t.seed), item, f, g + 1)
+                    same += int(draw(pl[f, g, k].numpy(), spd, ug) == draw(pl32[f, g, k].numpy(), spd, ug))
+        print(f"bf16 oracle draws equal to the float32 oracle's: {same}/{tot} = {same / tot:.4f}")
+        assert hit / tot >= same / tot - 0.06 and hit / tot >= 0.7, (hit, same, tot)
+    finally:
+        t.close()
