@@ -354,6 +354,29 @@ RT_API int rt_stt_transcribe(rt_stt* s, const float* d_pcm, int64_t n_samples, i
 RT_API int rt_stt_log_mel(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, float* d_mel);
 RT_API int rt_stt_encode(rt_stt* s, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, float* d_states);
 
+/* ------------------------------------------------------------------ drift-classifier features
+ * Stands behind the front half of validation/classifier/trainer.py:23-96 (extract_features, _estimate_formants: librosa on a
+ * temporary WAV): the per-sample work of the 30 hand-crafted dimensions, on the waveform where it lives.
+ *   d_pcm: mono float32 in HBM at sample_rate_in; resampled to 16 kHz on the device (the speech-to-text front-end's resampler).
+ *   h_mfcc_stats26: mean (13) then population standard deviation (13) over the frames of the 13 MFCCs (n_fft 2048, hop 512,
+ *     zero-padded centre, periodic Hann, 128 slaney mel filters, power_to_db with top_db 80, orthonormal DCT-II).
+ *   h_cmnd [n_frames][max_period - min_period + 1] float64 (optional, room for cmnd_cap_frames frames): the cumulative-mean-
+ *     normalised difference function of probabilistic YIN per pitch frame (frame 2048, window 1024, hop 512, zero-padded
+ *     centre) for the lags min_period .. max_period (rt_features_geometry); the trough statistics and the Viterbi pass that
+ *     turn it into F0 are host arithmetic (rho_tts_amd/features.py).
+ *   h_lpc [lpc_order + 1] float64: Burg LPC of the pre-emphasised (0.97), symmetric-Hann-windowed 25-ms frame about the middle
+ *     sample; the formants are the angles of its roots.
+ * Frames: 1 + n16 / 512 for both (n16 = samples at 16 kHz).  Parity with librosa is UNPINNED (not installable offline). */
+typedef struct rt_features rt_features;
+RT_API int rt_features_create(rt_ctx* ctx, rt_features** out);
+RT_API int rt_features_destroy(rt_features* f);
+/* min / max period of probabilistic YIN for a search range [fmin, fmax] Hz at the rate the analysis ASSUMES (the reference
+ * leaves librosa.pyin's default 22050 in place for 16-kHz audio, trainer.py:52): floor(sr / fmax), min(ceil(sr / fmin), 1023). */
+RT_API int rt_features_geometry(int32_t pitch_sr, double fmin, double fmax, int32_t* min_period, int32_t* max_period);
+RT_API int rt_features_extract(rt_features* f, const float* d_pcm, int64_t n_samples, int32_t sample_rate_in, int32_t min_period,
+                               int32_t max_period, int32_t lpc_order, double* h_mfcc_stats26, int32_t* h_n_mfcc_frames, double* h_cmnd,
+                               int32_t cmnd_cap_frames, int32_t* h_n_pitch_frames, double* h_lpc);
+
 /* Measurement and test entry points (rt_profile_*, rt_debug_*, rt_bench_*) are declared in rho_tts_amd_debug.h: a host binding of
  * the generation path needs none of them. */
 

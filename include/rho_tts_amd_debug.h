@@ -87,7 +87,7 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   90n prefill split-K target of n workgroups per CU | 1000/1001 XCD-aware tile order of the tiled GEMM off/on |
  *   1300/1301 stream sync after every decode frame part off/on (bounds the dispatches in flight under rocprofv3 --pmc) |
  *   14nn end-of-sequence flags fetched every nn frames (default 8; 1401 = a copy + wait per frame) |
- *   1500/1501 shared-prefix decode attention on the vector unit / on the matrix cores | 1600/1601 quarter-tile split off/on |
+ *   1500/1501/1502 shared-prefix decode attention on the vector unit / on the matrix cores with four rows / one row per workgroup | 1600/1601 quarter-tile split off/on |
  *   17nn queued items (rt_generate with n_items > max_batch) take over finished rows every nn frames (default 4) |
  *   20nn batches of up to nn rows (default 64) decode on the column-owner path, larger ones on the legacy split-K path |
  *   1900/1901/1902/1903 prompt-prefill GEMMs on the split-K tiled kernel / on k_gemm_mid (automatic, 64 x 64, 128 x 128 tiles) |
@@ -95,8 +95,7 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   2100/2101 the codec decoder's 96-channel residual units as two launches (k = 7 conv, 1x1 conv) / one fused launch |
  *   2200/2201 prompt-prefill attention behind a shared voice prefix on the vector unit / on the matrix cores |
  *   2300/2301 decode GEMMs of <= 16 rows on the 32-row / the two-workgroups-per-CU 16-row instantiation |
- *   2400/2401 gate/up decode GEMM whose tile pairs are 1.5x the CUs: one pair per workgroup (1.5 rounds) / 1.5 pairs per workgroup (one round) |
- *   2500/2501 the decode frame counter advanced by a launch of its own / by the talker step's last GEMM launch
+ *   2400/2401 gate/up decode GEMM whose tile pairs are 1.5x the CUs: one pair per workgroup (1.5 rounds) / 1.5 pairs per workgroup (one round)
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);

@@ -58,7 +58,7 @@ template <int ROWS, int NW, bool PREFILL>
 __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
     constexpr int QR = ROWS * REP;                                         // live query vectors of the 16 MFMA columns
     constexpr int WPR = NW / ROWS;                                         // waves per row for the rows' own positions
-    static_assert(QR <= 16 && NW % ROWS == 0 && (PREFILL || NW == 4 * ROWS), "wave layout");
+    static_assert(QR <= 16 && NW % ROWS == 0 && (PREFILL || NW >= 4 * ROWS), "wave layout");
     constexpr int QP = D + 8;                                              // row pitch 272 B: the 16 rows of a b128 fragment read land on distinct banks
     __shared__ __attribute__((aligned(16))) bf16_t sq_hi[16][QP];         // Q (scaled), bf16 hi / lo planes, rows >= QR zero
     __shared__ __attribute__((aligned(16))) bf16_t sq_lo[16][QP];
@@ -77,6 +77,26 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
 
     // ---------------------------------------------------------------- A: fused prologue, one vector per wave
     for (int t = tid; t < 16 * QP; t += NW * 64) { (&sq_hi[0][0])[t] = 0; (&sq_lo[0][0])[t] = 0; }
+    // decode: the operands of the wave's prologue vector (q / k / v of the new position, norm weights, RoPE factors) are requested
+    // FIRST - vector-memory loads return in issue order, so behind the 16 KiB of prefix tiles below they would arrive last - and
+    // without branches (clamped row, stand-in pointers): waves past 4 x ROWS load a vector they never use
+    constexpr int half_d = D / 2;
+    float pro_a = 0.f, pro_b = 0.f, pro_wa = 1.f, pro_wb = 1.f, pro_c = 1.f, pro_s = 0.f;
+    int pro_hi = 0, pro_slot = 0;
+    if constexpr (!PREFILL) {
+        const int rr = (w >> 2) < ROWS ? (w >> 2) : ROWS - 1, vec = w & 3;
+        const int row = r0 + rr < g.M ? r0 + rr : g.M - 1;
+        const int width = (heads + 2 * kv_heads) * D;
+        const int col0 = vec < REP ? (kh * REP + vec) * D : (vec == REP ? (heads + kh) * D : (heads + kv_heads + kh) * D);
+        const float* src = g.qkv + (int64_t)row * width + col0;
+        pro_a = src[lane]; pro_b = src[lane + half_d];
+        const float* nw = vec < REP ? g.qw : g.kw;
+        const float* nwp = nw ? nw : src;
+        pro_wa = nwp[lane]; pro_wb = nwp[lane + half_d];
+        pro_hi = g.row_pos[row] + g.pos_add + frame;
+        pro_slot = g.row_slot[row];
+        pro_c = g.cosT[(int64_t)pro_hi * half_d + lane]; pro_s = g.sinT[(int64_t)pro_hi * half_d + lane];
+    }
     // the wave's first prefix block is requested BEFORE the prologue: it depends on nothing the prologue produces, so its L2
     // round trip runs under the prologue's own loads and reductions
     int Lp = g.prefix_len;
@@ -119,23 +139,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
     } else {
         const int rr = w >> 2, vec = w & 3;                 // local row, vector: 0,1 = the two query heads, 2 = K, 3 = V
         const int row = r0 + rr;
-        if (row < g.M) {
+        if (rr < ROWS && row < g.M) {
             constexpr int half = D / 2;
-            const int width = (heads + 2 * kv_heads) * D;
             const bool is_q = vec < REP, is_k = vec == REP;
-            const int col0 = is_q ? (kh * REP + vec) * D : (is_k ? (heads + kh) * D : (heads + kv_heads + kh) * D);
-            const int hi = g.row_pos[row] + g.pos_add + frame, slot = g.row_slot[row];
+            const int hi = pro_hi, slot = pro_slot;
             if (vec == 0 && lane == 0) s_hi[rr] = hi;
-            float a = g.qkv[(int64_t)row * width + col0 + lane], b = g.qkv[(int64_t)row * width + col0 + lane + half];
+            float a = pro_a, b = pro_b;
             if (is_q || is_k) {
                 const float* nw = is_q ? g.qw : g.kw;
                 if (nw) {
                     const float ss = wave_sum_f32(a * a + b * b);
                     const float inv = rsqrtf(ss / (float)D + g.eps);
-                    a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv);
+                    a = pro_wa * (a * inv); b = pro_wb * (b * inv);
                 }
-                const float c = g.cosT[(int64_t)hi * half + lane], s = g.sinT[(int64_t)hi * half + lane];
-                const float ra = a * c - b * s, rb = b * c + a * s;
+                const float ra = a * pro_c - b * pro_s, rb = b * pro_c + a * pro_s;
                 a = ra; b = rb;
             }
             if (is_q) {
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
                 o[lane] = ra; o[lane + half] = rb;
                 s_kv[rr][is_k ? 0 : 1][lane] = ra; s_kv[rr][is_k ? 0 : 1][lane + half] = rb;
             }
-        } else if (vec == 0 && lane == 0) {
+        } else if (rr < ROWS && vec == 0 && lane == 0) {
             s_hi[rr] = -1;
         }
     }
@@ -416,7 +433,14 @@ int launch_attention_prefix_mfma(rt_ctx* ctx, const float* qkv, int M, int heads
     g.kt = kv.kt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt = kv.vt_prefix + (int64_t)layer * kv_heads * kv.vt_stride; g.vt_stride = kv.vt_stride;
     g.out = out; g.qw = q_norm_w; g.kw = k_norm_w; g.eps = eps; g.cosT = rope_cos; g.sinT = rope_sin; g.frame_ptr = frame_ptr; g.out_tiled = out_tiled;
     g.prefix_slot = kv.prefix_slot; g.prefix_len = kv.prefix_len;
-    hipLaunchKernelGGL((k_attn_prefix_mfma<4, 16, false>), dim3(kv_heads, (M + 3) / 4), dim3(16 * 64), 0, ctx->stream, g);
+    // g_attn_mfma 1: four rows per workgroup (the prefix tiles read once per four rows, 64 workgroups at batch 32: round 2's form);
+    // 2: ONE row per workgroup - the grid of the vector-unit kernel (a workgroup per (row, kv head), every CU busy), each of the 16
+    // waves multiplies one 32-key prefix block on the matrix cores and all 16 share the row's own positions.  The prefix tiles are
+    // re-read per row from L2 like the cache rows of the vector kernel, which the counters show is not what bounds it
+    // (profiles/r04_pmc_attention.csv: 33 MB of L2 -> L1 reads in a 12.9-us launch); what the matrix cores remove is the vector unit's
+    // 2.8 us of dot products and rescales over the 460 prefix keys.
+    if (g_attn_mfma == 2) hipLaunchKernelGGL((k_attn_prefix_mfma<1, 16, false>), dim3(kv_heads, M), dim3(16 * 64), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((k_attn_prefix_mfma<4, 16, false>), dim3(kv_heads, (M + 3) / 4), dim3(16 * 64), 0, ctx->stream, g);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -303,7 +303,6 @@ int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
     // flight keeps the plan it began with - the switch is refused rather than applied under it
     std::unique_lock<std::shared_mutex> all(g_tune_mu);
     if (g_runs_in_flight.load() > 0) return RT_ERR_STATE;
-    if (skinny_variant >= 2500) { g_fold_frame_inc = skinny_variant - 2500; return RT_OK; }        // 2500/2501: frame counter advanced by k_frame_inc / by the talker step's last GEMM launch
     if (skinny_variant >= 2400) { g_col_silu_x = skinny_variant - 2400; return RT_OK; }            // 2400/2401: gate/up decode GEMM as pairs in 1.5 rounds / as one round of 1.5-pair workgroups
     if (skinny_variant >= 2300) { g_col_rows16 = skinny_variant - 2300; return RT_OK; }           // 2300/2301: <= 16-row decode GEMMs on the 32-row / the 2-workgroups-per-CU 16-row instantiation
     if (skinny_variant >= 2200) { g_prefill_attn_mfma = skinny_variant - 2200; return RT_OK; }    // 2200/2201: prompt attention behind a shared prefix on the vector unit / matrix cores
@@ -313,7 +312,7 @@ int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
     if (skinny_variant >= 1800) { g_conv_tall = skinny_variant - 1800; return RT_OK; }           // 1800/1801: 128- / 256-row tiles for the narrow-channel k>1 convs
     if (skinny_variant >= 1700) { g_handover_every = std::max(1, skinny_variant - 1700); return RT_OK; }  // 17nn: queued items take over finished rows every nn frames
     if (skinny_variant >= 1600) { g_col_split4 = skinny_variant - 1600; return RT_OK; }           // 1600/1601: quarter-tile split of N <= 1024 decode GEMMs off/on
-    if (skinny_variant >= 1500) { g_attn_mfma = skinny_variant - 1500; return RT_OK; }            // 1500/1501: MFMA shared-prefix decode attention off/on
+    if (skinny_variant >= 1500) { g_attn_mfma = skinny_variant - 1500; return RT_OK; }            // 1500/1501/1502: shared-prefix decode attention on the vector unit / matrix cores, 4 rows per workgroup / matrix cores, 1 row
     if (skinny_variant >= 1400) { g_eos_check_every = std::max(1, skinny_variant - 1400); return RT_OK; }   // 14nn: look at the end-of-sequence flags every nn frames
     if (skinny_variant >= 1300) { g_sync_parts = skinny_variant - 1300; return RT_OK; }             // 1300/1301: stream sync after every frame part off/on
     if (skinny_variant >= 1200) { g_conv_win = skinny_variant - 1200; return RT_OK; }               // 1200/1201: conv input window in LDS off/on
@@ -548,6 +547,16 @@ int rt_bench_attention_fused(rt_ctx* ctx, int32_t M, int32_t heads, int32_t kv_h
     for (int i = 0; i < M; ++i) hs[i] = i;
     RT_HIP(ctx, hipMemcpyAsync(pos, hp.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(slot, hs.data(), (size_t)M * 4, hipMemcpyHostToDevice, ctx->stream));
+    bf16_t* tiles = nullptr;
+    if (kv.prefix_slot >= 0 && prefix_len >= 64 && head_dim == 128) {      // fragment-tiled prefix copies: what the matrix-core forms read
+        kv.vt_stride = (prefix_len + 31) / 32 * 4096;
+        kv.prefix_slot_alloc = kv.prefix_slot;
+        RT_HIP(ctx, hipMalloc((void**)&tiles, (size_t)2 * layers * kv_heads * kv.vt_stride * 2));
+        kv.kt_prefix = tiles;
+        kv.vt_prefix = tiles + (size_t)layers * kv_heads * kv.vt_stride;
+        const int rt = launch_transpose_prefix_v(ctx, kv, prefix_len);
+        if (rt) return rt;
+    }
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipEvent_t e0, e1;
     RT_HIP(ctx, hipEventCreate(&e0));
@@ -566,7 +575,7 @@ int rt_bench_attention_fused(rt_ctx* ctx, int32_t M, int32_t heads, int32_t kv_h
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1e3 / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (void* p : {(void*)kv.k, (void*)kv.v, (void*)qkv, (void*)cs, (void*)nw, (void*)pos, (void*)slot, (void*)out}) (void)hipFree(p);
+    for (void* p : {(void*)kv.k, (void*)kv.v, (void*)qkv, (void*)cs, (void*)nw, (void*)pos, (void*)slot, (void*)out, (void*)tiles}) if (p) (void)hipFree(p);
     return rc;
 }
 

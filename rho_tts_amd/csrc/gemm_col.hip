@@ -279,7 +279,6 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
         }
     }
     if (g.stamps && blockIdx.x == 0 && tid == 0) g.stamps[5] = wall_clock64();
-    if (g.inc_i32 && blockIdx.x == 0 && tid == 0) *g.inc_i32 += 1;
 }
 
 template <int EPI, int MT, int NPRE, bool X, bool NORM>
@@ -332,7 +331,6 @@ int dispatch_epi(rt_ctx* ctx, const ColArgs& g, dim3 grid, hipEvent_t e0, hipEve
 // re-reads the whole A operand), so that split is only taken when forced through rt_debug_tune(502/504); the 1.5 rounds
 // are evened out the other way - fewer, larger workgroups (X, g_col_silu_x).
 rt_knob g_col_silu_x{1};            // 1: gate/up GEMMs whose pairs are 1.5x the CUs run as one round of 1.5-pair workgroups (rt_debug_tune 2400 / 2401)
-rt_knob g_fold_frame_inc{1};        // 1: the decode frame counter rides on the last GEMM launch of the talker step (0: k_frame_inc, its own launch)
 rt_knob g_col_rows16{0};            // 1: launches of <= 16 rows take the 128-VGPR MT = 1 instantiation (two workgroups per CU: decode lanes, rt_debug_tune 2301)
 rt_knob g_col_split4{0};            // quarter tiles for N <= 1024 measured 1.4 ms/step slower than half tiles (rt_debug_tune 1601 to try)
 int col_split_silu(int N, int n_cu) {

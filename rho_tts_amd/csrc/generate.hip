@@ -286,7 +286,7 @@ int rt_gen_run::init(const rt_generate_args* a) {
                 mix((uint64_t)(uintptr_t)p);
                 mix(ln.b0); mix(ln.n);
             }
-        mix(B); mix(col); mix(n_lanes); mix(A.ignore_eos); mix(A.min_frames); mix(g_attn_mfma); mix(g_col_split); mix(g_col_split4); mix(g_col_rows64); mix(g_col_rows16); mix(g_col_silu_x); mix(g_fuse_sample_embed); mix(g_fold_frame_inc);
+        mix(B); mix(col); mix(n_lanes); mix(A.ignore_eos); mix(A.min_frames); mix(g_attn_mfma); mix(g_col_split); mix(g_col_split4); mix(g_col_rows64); mix(g_col_rows16); mix(g_col_silu_x); mix(g_fuse_sample_embed);
         // the attention nodes carry the voice prefix (slot, length) by value: a voice of another length must not replay the
         // old graphs.  The prefix KV *content* is read through pointers, so re-setting a voice of the same length keeps them.
         mix((uint64_t)Lp); mix((uint64_t)(int64_t)m->talker.kv.prefix_slot);
@@ -492,18 +492,17 @@ int rt_gen_run::enqueue_b(Lane& ln) {
         RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes, n, H, pad_t, nullptr, nullptr, ln.xt, nullptr, G, ln.d_frame, codes_fs));
         if (col) RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.L[0].ln1));
     }
-    // frame += 1: on the column path the talker step's last launch (the last layer's down projection, which does not read the
-    // counter) advances it - one launch per frame less than with k_frame_inc
-    const bool fold = col && g_fold_frame_inc;
     if (col) {
-        RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, 0, true, ln.d_frame, -1, false, fold ? ln.d_frame : nullptr));
+        RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, 0, true, ln.d_frame));
     } else {
         RT_TRY(stack_forward(m, m->talker, ln.wt, ln.xt, n, ln.d_slot_b, ln.d_pos_b, 0, ln.hn, ln.hn_f32, ln.d_frame));
     }
-    if (!fold) {
-        hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, ln.d_frame);
-        RT_HIP(ctx, hipGetLastError());
-    }
+    // frame += 1 stays a launch of its own.  Letting the talker step's last GEMM launch advance the counter (one thread of a launch
+    // that does not read it; round 4) measured SLOWER, not faster: 204.56 / 203.23 ms per step folded against 203.98 / 202.65 with
+    // this 3.9-us launch, A/B on one box - the extra kernel argument and tail branch cost each of the 18 764 GEMM launches of a
+    // step more than the 44 launches saved.
+    hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, ln.d_frame);
+    RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 

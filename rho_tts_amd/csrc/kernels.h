@@ -101,7 +101,6 @@ extern rt_knob g_col_rows64;          // 1: decode GEMM launches take up to 64 r
 extern rt_knob g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
 extern rt_knob g_col_split4;
 extern rt_knob g_col_silu_x;         // 1: 1.5-pair gate/up workgroups when the pairs are 1.5x the CUs
-extern rt_knob g_fold_frame_inc;    // 1: the frame counter is advanced by the talker step's last GEMM launch (rt_debug_tune 2500 / 2501)
 extern rt_knob g_col_rows16;         // 1: <= 16-row decode GEMM launches on the two-workgroups-per-CU instantiation (decode lanes)          // 1: the automatic split may go to quarter tiles (N <= 1024 on 256 CUs)
 int col_split_for(int N, int n_cu);
 int col_split_silu(int N, int n_cu);
@@ -134,8 +133,6 @@ struct ColArgs {
     int rowsq_out_n = 0;
     bf16_t* out_bf16 = nullptr;     // SILU: act [M][ldc]
     long long* stamps = nullptr;    // debug: 100-MHz wall-clock stamps of workgroup 0 at the phase boundaries
-    int32_t* inc_i32 = nullptr;     // optional: one thread adds 1 to this word when the launch ends - the decode frame counter rides on the
-                                    // frame's LAST launch (no workgroup of that launch reads it) instead of a launch of its own
     // filled by the launcher
     const bf16_t* Wp = nullptr;
     int NT = 0, KT = 0, N = 0, up_tile_offset = 0;

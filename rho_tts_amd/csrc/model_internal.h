@@ -151,8 +151,7 @@ int stack_forward(rt_model* m, StackW& S, StackWs& w, float* x, int M, const int
 int alloc_dec_ws(rt_model* m, const rt_stack_dims& d, int M, DecWs* w);
 int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor = false);
 int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
-                 int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr, int slot_base = -1, bool zero_pos = false,
-                 int32_t* inc_after = nullptr);      // inc_after: a word the stack's LAST launch advances by one (the frame counter)
+                 int pos_add, bool one_row_per_slot = true, const int32_t* frame_ptr = nullptr, int slot_base = -1, bool zero_pos = false);
 int col_head(rt_model* m, const bf16_t* xa, const float* rowsq, int rowsq_n, int row_off, int M, int K, float eps,
              const PackedW& W, const float* bias, float* out);
 int alloc_text_ws(rt_model* m, int n, TextWs* w);

@@ -182,7 +182,6 @@ int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor
         a.nt = is_predictor ? g_pred_nt.load() : 1;
         a.M = std::min(blk, a0.M - r0);
         a.row_off = a0.row_off + r0;
-        if (r0 + blk < a0.M) a.inc_i32 = nullptr;          // (an optional counter is advanced once, by the last row block's launch)
         hipEvent_t e0, e1;
         prof_events(m, (double)W.N * W.K * 2.0, &e0, &e1);
         RT_TRY(launch_gemm_col(m->ctx, a, W, e0, e1));
@@ -192,7 +191,7 @@ int col_gemm(rt_model* m, const ColArgs& a0, const PackedW& W, bool is_predictor
 // one_row_per_slot = false (the predictor's 2-row first pass): a row must see the K/V another row of the same launch
 // appends, so q/k-norm + RoPE + append run as their own launch before the attention.
 int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M, const int32_t* row_slot, const int32_t* row_pos,
-                 int pos_add, bool one_row_per_slot, const int32_t* frame_ptr, int slot_base, bool zero_pos, int32_t* inc_after) {
+                 int pos_add, bool one_row_per_slot, const int32_t* frame_ptr, int slot_base, bool zero_pos) {
     rt_ctx* ctx = m->ctx;
     const rt_stack_dims& d = S.d;
     const int H = d.hidden, sp_h = col_split_for(H, ctx->n_cu), NTh = H / 16 * sp_h, qw = (d.heads + 2 * d.kv_heads) * d.head_dim;
@@ -225,7 +224,6 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
         ColArgs dn;     // x += ls2 .* (act Wd^T); emits rowsq and bf16(next norm .* x)
         dn.A = w.act; dn.M = M; dn.K = d.inter; dn.epi = COL_RESID; dn.out = x; dn.ldc = H; dn.scale = L.ls2;
         dn.rowsq_out = rowsq; dn.rowsq_out_n = NTh; dn.next_bf16 = w.xa; dn.next_norm_w = next_w; dn.split = sp_h;
-        if (i + 1 == d.layers) dn.inc_i32 = inc_after;
         RT_TRY(col_gemm(m, dn, L.wd, isp));
         if (g_sync_parts && !g_use_graph) RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }

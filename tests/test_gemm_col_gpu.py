@@ -200,10 +200,10 @@ def rope_ref(x, pos, theta, d):
     (64, 4, 4, 256, 5, 33, 33, 100),           # REP 1, head_dim 64, prefix end inside a 128-B line
     (32, 4, 1, 128, 3, 7, 7, 60),              # REP 4 (no early batch), head_dim 32
 ])
-@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("mfma", [0, 1, 2])
 def test_fused_attention_matches_fp32(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo, pos_hi, mfma):
-    """mfma = 1 routes the head_dim-128 shared-prefix cases through the matrix-core kernel (attention_mfma.hip, rt_debug_tune
-    1501; off by default: it measured slower than the vector-unit kernel), the others are unaffected by the switch."""
+    """mfma = 1 / 2 route the head_dim-128 shared-prefix cases through the matrix-core kernel (attention_mfma.hip, rt_debug_tune
+    1501: four rows per workgroup, 1502: one row per workgroup), the others are unaffected by the switch."""
     if mfma and not (d == 128 and Lp >= 64):
         pytest.skip("the matrix-core path exists for head_dim 128 with a shared prefix only")
     ctx.lib.rt_debug_tune(1500 + mfma, 0)
@@ -275,7 +275,7 @@ def _fused_attention_matches_fp32(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo, po
     (64, 4, 4, 512, 6, 130, 130, 400),         # head_dim 64 (two cache rows per 128-B line)
     (32, 4, 1, 256, 4, 9, 9, 200),             # REP 4
 ])
-@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("mfma", [0, 1, 2])
 def test_fused_attention_key_census(ctx, d, heads, kvh, max_pos, M, Lp, pos_lo, pos_hi, mfma):
     if mfma and not (d == 128 and Lp >= 64):
         pytest.skip("the matrix-core path exists for head_dim 128 with a shared prefix only")

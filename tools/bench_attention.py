@@ -23,6 +23,7 @@ def run(M, heads, kvh, d, prefix, own, shared, layers=28, iters=560):
     return us.value if rc == 0 else float("nan")
 
 
+print("tune codes:", sys.argv[1:] or "(defaults)", flush=True)
 print("talker decode attention, 32 rows x 8 kv heads x 2 q heads x 128, 28 layers cycled: us per launch", flush=True)
 print(f"{'prefix':>7} {'own':>4} {'shared us':>10} {'unshared us':>12}", flush=True)
 for prefix in (0, 64, 128, 256, 460):
