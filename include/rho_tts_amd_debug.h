@@ -45,7 +45,7 @@ RT_API int rt_debug_gemm(rt_ctx* ctx, const void* d_a, int32_t a_is_f32, int64_t
 RT_API int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, int32_t kv_heads, int32_t head_dim,
                               const int32_t* d_row_slot, const int32_t* d_row_pos, int32_t window, const void* d_k, const void* d_v,
                               int32_t slots, int32_t max_pos, void* d_out_bf16);
-/* The dominant decode kernel on its own (gemm_col.hip k_gemm_col; launched as model.hip launches it: row blocks of <= 64,
+/* The dominant decode kernel on its own (gemm_col.hip k_gemm_col; launched as model_stack.hip launches it: row blocks of <= 64,
  * production sub-tile split when split = 0).  Row-major operands; the hook converts to / from the fragment-tiled layout.
  *   A [M][K] bf16, W [N][K] bf16 (epi 2: gate rows [0, N/2) then up rows), M <= 64, K % 32 == 0, row_off % 16 == 0
  *   d_rowsq [M][rowsq_n] or NULL: partial sums of squares of the pre-norm row; acc rows are scaled by rsqrt(sum/K + eps)

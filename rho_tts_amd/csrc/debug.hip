@@ -114,7 +114,7 @@ int rt_debug_attention(rt_ctx* ctx, const float* d_q, int32_t M, int32_t heads, 
     return rc;
 }
 
-// The column-owner decode GEMM (k_gemm_col) on its own, launched exactly as model.hip's col_gemm launches it (row blocks of
+// The column-owner decode GEMM (k_gemm_col) on its own, launched exactly as model_stack.hip's col_gemm launches it (row blocks of
 // 64 / 32, the production sub-tile split unless one is forced).  Row-major operands at the ABI; the hook tiles / un-tiles.
 int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32_t K, const void* d_w_bf16, int32_t N, int32_t epi, int32_t split,
                       int32_t row_off, int32_t nt, const float* d_rowsq, int32_t rowsq_n, float eps, const float* d_bias, const float* d_scale,
@@ -175,7 +175,7 @@ int rt_debug_gemm_col(rt_ctx* ctx, const void* d_a_bf16, int32_t M, int32_t K, c
         c.out_bf16 = act_t;
     }
     const int blk = g_col_rows64 ? 64 : 32;
-    for (int r0 = 0; r0 < M && !rc; r0 += blk) {                 // model.hip col_gemm
+    for (int r0 = 0; r0 < M && !rc; r0 += blk) {                 // model_stack.hip col_gemm
         ColArgs a = c;
         a.M = std::min(blk, M - r0);
         a.row_off = row_off + r0;

@@ -7,7 +7,7 @@ Input: the counter_collection CSV of
 (200 = eager launches, 1301 = a host wait per layer: rocprofv3's counter collection on this image faults once a few hundred
 dispatches are queued un-waited - tools/pmc_probe.py flood / syncflood).
 
-The k_gemm_col dispatches of a decode frame come in a fixed order (model.hip enqueue_a / enqueue_b):
+The k_gemm_col dispatches of a decode frame come in a fixed order (generate.hip enqueue_a / enqueue_b):
     part A: talker head, mtp projection, predictor pass 0 (5 layers x 4 GEMMs, 64-row launches),
             then 15 x [predictor head g, (5 layers x 4 GEMMs) for g < 14]
     part B: 28 talker layers x 4 GEMMs            (not run after the last frame)
