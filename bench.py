@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PMC_PROFILE = "r03_pmc_fetch_bench_step.json"      # counter pass over this bench's own step (tools/pmc_step_split.py), keyed on the library's hash
+PMC_PROFILE = "r04_pmc_fetch_bench_step.json"      # counter pass over this bench's own step (tools/pmc_step_split.py), keyed on the library's hash
 
 WORDS = ("time year people way day man thing woman life child world school state family student group country problem hand "
          "part place case week company system program question work government number night point home water room mother area "

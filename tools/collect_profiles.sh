@@ -5,7 +5,7 @@
 # faults once a few hundred dispatches are queued un-waited (tools/pmc_probe.py).  No --pmc run is combined with any trace domain
 # other than --kernel-trace.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -38,4 +38,7 @@ python3 $ROOT/tools/family_summary.py --trace $P/t --trace-steps 3 --fetch $P/f 
 echo "[6] L1 / L2 read requests of the decode GEMM shapes (A operand against weights)"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/l -- python3 $ROOT/tools/bench_gemm_col.py > $OUT/l_bench.log 2>&1
 python3 $ROOT/tools/pmc_by_kernel.py $P/l k_gemm_col > $OUT/pmc_gemm_col_l1.csv 2>/dev/null && head -20 $OUT/pmc_gemm_col_l1.csv
+echo "[7] L1 / L2 read requests of the decode attention (one bench step)"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $P/q -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --tune 200,1301 > $OUT/q_bench.log 2>&1
+python3 $ROOT/tools/pmc_by_kernel.py $P/q k_attention > $OUT/pmc_attention.csv 2>/dev/null && cat $OUT/pmc_attention.csv
 echo done
