@@ -348,3 +348,19 @@ def test_bench_one_gpu_direct_and_under_the_launcher_agree():
     assert direct["ranks"]["rccl_ranks_seen"] is None and direct["ranks"]["world"] == 1
     assert ranked["ranks"] == dict(ranked["ranks"], world=1, backend="nccl", rccl_ranks_seen=1)
     assert abs(direct["value"] - ranked["value"]) <= 0.03 * direct["value"], (direct["value"], ranked["value"])
+
+
+def test_pinned_ring_views_live_until_the_call_after_next():
+    """dist.waveforms_to_host(copy=False) hands out views of a two-buffer pinned ring (bench.py reads a step's waveforms before the
+    step after next): the views of one call survive the next call and equal the copying form's result."""
+    from rho_tts_amd import dist as D
+    g = torch.Generator().manual_seed(3)
+    a = [torch.randn(1000 + 37 * i, generator=g).cuda() for i in range(5)] + [None, torch.zeros(0).cuda()]
+    b = [torch.randn(777, generator=g).cuda()]
+    va = D.waveforms_to_host(a, copy=False)
+    keep = [None if w is None else w.clone() for w in va]
+    vb = D.waveforms_to_host(b, copy=False)                     # the other buffer of the ring
+    assert all((x is None and y is None) or torch.equal(x, y) for x, y in zip(va, keep))
+    assert torch.equal(vb[0], b[0].cpu()) and va[5] is None and va[6].numel() == 0
+    ca = D.waveforms_to_host(a, copy=True)
+    assert all((x is None and y is None) or torch.equal(x, y.cpu()) for x, y in zip(ca, a))
