@@ -150,7 +150,12 @@ RT_API int rt_pcm16(rt_ctx* ctx, const float* d_in, int64_t n, int16_t* d_out);
  * per-segment leaves of stream() (base_tts.py:1170-1176: _post_process_audio, _trim_silence, _remove_dc_offset, _apply_fades)
  * for ONE chunk of a segment that is still being decoded.  The two segment-wide quantities are taken from the segment's first
  * chunk and carried: h_dc_gain[0] = DC offset, h_dc_gain[1] = linear gain to the target RMS (in/out).
- *   RT_STREAM_MEASURE     first chunk: measure gain (on the raw chunk) and dc (after the trim) and return them; else apply as given
+ *   RT_STREAM_MEASURE     first chunk: measure gain (target RMS / RMS of the raw chunk's AUDIBLE span - first to last 10-ms frame above
+ *                         the silence threshold - held to +-30 dB; over the WHOLE chunk, unclamped, when the chunk is also the last: a
+ *                         segment handed over whole is levelled as the reference levels it) and dc (after the trim) and return
+ *                         them; else apply as given.
+ *                         A chunk with no audible frame measures nothing and returns gain 0: pass RT_STREAM_MEASURE (with the
+ *                         first-chunk trim and fade flags) again with the next chunk and drop this one's output
  *   RT_STREAM_TRIM_START  drop leading silence (first chunk)     RT_STREAM_TRIM_END  drop trailing silence (last chunk)
  *   RT_STREAM_FADE_IN / _OUT  raised-cosine ramps of p->fade samples at the chunk's start / end (skipped below 2 x fade samples)
  * y = 0.95 tanh(x gain / 0.95) - dc; the 2-s windowed decay correction needs the whole segment and is not applied.

@@ -214,7 +214,9 @@ class Context:
 
     def stream_chunk(self, params: PostParams, x, state, first: bool, last: bool):
         """rt_stream_chunk: the per-segment leaves for one chunk of a segment still being decoded.  ``state`` is the segment's
-        ``[dc, gain]`` list: written by the first chunk, applied by the later ones.  Returns the processed chunk (GPU tensor)."""
+        ``[dc, gain]`` list: written by the first chunk that holds audible audio, applied by the later ones.  A ``first`` chunk
+        without an audible frame leaves ``state[1] == 0``: drop its output and pass ``first=True`` again with the next chunk.
+        Returns the processed chunk (GPU tensor)."""
         import torch
         x = x.detach().reshape(-1).to(torch.float32).contiguous()
         if not x.is_cuda:

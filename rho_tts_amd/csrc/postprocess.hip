@@ -404,9 +404,11 @@ __global__ void k_pcm16(const float* __restrict__ in, int64_t n, int16_t* __rest
 // base_tts.py:1170-1176: loudness (global gain to the target RMS + tanh soft clip, qwen.py:296-310), silence trim, DC removal,
 // fades), with the two segment-wide quantities carried from the segment's first chunk instead of being measured on audio that
 // does not exist yet:
-//   gain  MEASURED on the first chunk (target RMS / RMS of the raw chunk), applied unchanged to the later ones - no gain step
-//         at a chunk boundary; the 2-s windowed decay correction needs the whole segment and is not part of streaming
-//   dc    MEASURED on the first chunk after its trim, subtracted from every chunk
+//   gain  MEASURED on the first chunk that holds audible audio (target RMS / RMS of the raw chunk's audible span, held to +-30 dB;
+//         a chunk with no audible frame measures nothing and reports gain 0: the caller passes RT_STREAM_MEASURE again with the
+//         next one), applied unchanged to the later ones - no gain step at a chunk boundary; the 2-s windowed decay correction
+//         needs the whole segment and is not part of streaming
+//   dc    MEASURED on that chunk after its trim, subtracted from every chunk
 // Leading silence is trimmed from the first chunk, trailing silence from the last; fade-in / fade-out only at those two edges.
 // One 1024-thread workgroup per chunk, float64 reductions; frame energies (10-ms windows, hop 5 ms, count_include_pad as
 // avg_pool1d: base_tts.py:366-377) in float64.
@@ -418,10 +420,47 @@ __global__ __launch_bounds__(kThreads) void k_stream_chunk(rt_post_params P, con
     __shared__ long long sh_first, sh_last;
     double gain_d = st->gain, dc_d = st->dc;
     const float amp = (float)P.max_amplitude;
+    bool measured = true;
     if (flags & RT_STREAM_MEASURE) {
-        const double ss = block_sum(sumsq_range(x, 0, n), sh_red);
-        const double rms = sqrt(ss / (double)(n > 0 ? n : 1));
-        gain_d = rms > 1e-8 ? pow(10.0, (P.target_rms_db - 20.0 * log10(rms)) / 20.0) : 1.0;
+        // The segment-wide gain comes from the AUDIBLE span of this chunk - from the first to the last 10-ms frame of the RAW chunk
+        // above the silence threshold - not from the whole chunk: a first chunk is mostly lead-in silence and onset, and the RMS of
+        // all of it over-amplifies everything that follows into the soft clip.  No audible frame: nothing is measured, the state
+        // says so (gain 0) and the caller measures on the next chunk.  The gain is held to +-30 dB.
+        const int W = P.window, hop = W / 2;
+        const int64_t n_frames = n / hop + 1;
+        const double thr2 = (double)P.silence_threshold * (double)P.silence_threshold;
+        if (threadIdx.x == 0) { sh_first = n_frames; sh_last = -1; }
+        __syncthreads();
+        long long my_first = n_frames, my_last = -1;
+        for (int64_t f = threadIdx.x; f < n_frames; f += kThreads) {
+            int64_t a = f * hop - W / 2, b = a + W;
+            if (a < 0) a = 0;
+            if (b > n) b = n;
+            double acc = 0.0;
+            for (int64_t i = a; i < b; ++i) { const double v = (double)x[i]; acc += v * v; }
+            if (acc / (double)W > thr2) { if (f < my_first) my_first = f; if (f > my_last) my_last = f; }
+        }
+        atomicMin(&sh_first, my_first);
+        atomicMax(&sh_last, my_last);
+        __syncthreads();
+        const long long fa = sh_first, fb = sh_last;
+        __syncthreads();                                             // (sh_first / sh_last are reused by the trim below)
+        const bool whole = (flags & RT_STREAM_FADE_OUT) != 0;        // first AND last chunk: the whole segment is here - level it as the
+        if (fb < 0 && !whole) {                                      // reference levels a segment, over all of it (qwen.py:296-306)
+            measured = false;
+            gain_d = 1.0;
+        } else {
+            int64_t a = (int64_t)fa * hop;
+            int64_t b = ((int64_t)fb + 2) * hop;
+            if (b > n) b = n;
+            if (whole) { a = 0; b = n; }
+            const double ss = block_sum(sumsq_range(x, a, b), sh_red);
+            const double rms = sqrt(ss / (double)(b > a ? b - a : 1));
+            gain_d = rms > 1e-8 ? pow(10.0, (P.target_rms_db - 20.0 * log10(rms)) / 20.0) : 1.0;
+            if (!whole) gain_d = fmin(fmax(gain_d, 0.03162277660168379), 31.622776601683793);
+        }
+    } else if (!(gain_d > 0.0)) {
+        gain_d = 1.0;                                                // (a caller that never measured: unity)
     }
     const float gain = (float)gain_d;
     // trim bounds on the loudness-corrected chunk
@@ -466,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void k_stream_chunk(rt_post_params P, con
         if (fades && (flags & RT_STREAM_FADE_OUT) && i >= m - F) v = __fmul_rn(v, 0.5f * (1.0f + cosf(linspace_f32(0.f, 3.14159265358979323846f, F, (int)(i - (m - F))))));
         out[i] = v;
     }
-    if (threadIdx.x == 0) { st->dc = dc_d; st->gain = gain_d; st->out_len = m; st->start = lo; }
+    if (threadIdx.x == 0) { st->dc = measured ? dc_d : 0.0; st->gain = measured ? gain_d : 0.0; st->out_len = m; st->start = lo; }
 }
 
 int post_impl(rt_ctx* ctx, const rt_post_params* p, int32_t n_items, const int32_t* first, const float* const* seg_ptr,

@@ -814,14 +814,18 @@ class MI355XQwenTTS(DataParallelPipeline, HipAudioLeaves, BaseTTS):
             try:
                 with self._lock:
                     self._ensure_voice(eng)
-                    k = 0
+                    started = False                                  # audible audio of this segment has been handed out
                     for raw, last in eng.stream_wav(seg, seed=int(self.seed), item_id=0, first_chunk=int(self.stream_chunk_frames),
                                                     chunk=int(self.stream_next_chunk_frames), cancel_flag=flag):
                         if token.is_cancelled():
                             flag.value = 1
                             return
-                        audio = self._native_ctx().stream_chunk(params, raw, state, first=(k == 0), last=last) if raw.numel() else raw
-                        k += 1
+                        audio = self._native_ctx().stream_chunk(params, raw, state, first=not started, last=last) if raw.numel() else raw
+                        if not started and raw.numel():
+                            if state[1] > 0.0:
+                                started = True
+                            else:                                    # a chunk of lead-in silence: nothing measured, nothing to play -
+                                continue                             # the next chunk is the segment's first (gain, trim, fade-in)
                         if audio.numel() == 0:
                             continue
                         if speed != 1.0 or pitch_semitones != 0.0:

@@ -61,3 +61,28 @@ def test_scorer_hook_runs_on_the_waveform_in_hbm(ctx):
             ex(torch.zeros(1), 24000)
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("kind", ["silence", "short", "noise"])
+def test_feature_edge_cases(ctx, kind):
+    """All-zero audio (no voiced frame: F0 statistics 0, LPC = [1, 0, ...], no formant), a clip shorter than one analysis frame,
+    and white noise (pYIN mostly unvoiced): the extractor and the oracle agree, nothing is NaN."""
+    sr = 24000
+    if kind == "silence":
+        x = np.zeros(int(0.6 * sr), dtype=np.float32)
+    elif kind == "short":
+        x = voiced(0.05, sr, 200.0, seed=4)[-1000:]                     # 1000 samples at 24 kHz = 667 at 16 kHz: one padded frame + a partial one
+    else:
+        x = (0.1 * np.random.default_rng(5).standard_normal(int(0.5 * sr))).astype(np.float32)
+    ex = PF.HandcraftedFeatures(ctx)
+    try:
+        got = ex(torch.from_numpy(x).cuda(), sr)
+        ref = OF.handcrafted_features(x, sr)
+        assert got.shape == (30,) and np.all(np.isfinite(got)) and np.all(np.isfinite(ref))
+        assert float(np.abs(got[:26] - ref[:26]).max()) < 5e-3
+        assert abs(got[26] - ref[26]) <= 1e-6 * max(1.0, abs(ref[26])) and abs(got[27] - ref[27]) <= 1e-6 * max(1.0, abs(ref[27]))
+        assert abs(got[28] - ref[28]) < 1.0 and abs(got[29] - ref[29]) < 1.0
+        if kind == "silence":
+            assert got[26] == 0.0 and got[27] == 0.0 and got[28] == 0.0 and got[29] == 0.0
+    finally:
+        ex.close()

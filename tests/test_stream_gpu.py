@@ -45,16 +45,29 @@ def test_stream_chunk_matches_oracle(eng, cuts):
     p_cpu = OP.PostParams(sample_rate=24000)
     edges = [0] + cuts + [x.shape[0]]
     st_g, st_c = [0.0, 1.0], [0.0, 1.0]
+    started, silent_firsts = False, 0
     for k in range(len(edges) - 1):
         piece = x[edges[k]: edges[k + 1]]
-        first, last = k == 0, k == len(edges) - 2
+        first, last = not started, k == len(edges) - 2            # the caller's protocol: `first` until a chunk has measured the gain
         got = eng.ctx.stream_chunk(p_gpu, torch.from_numpy(piece).cuda(), st_g, first, last).cpu()
         want = OP.stream_chunk(piece, p_cpu, st_c, first, last)
         assert got.shape == want.shape, (k, got.shape, want.shape)
         assert abs(st_g[1] - st_c[1]) <= 1e-9 * abs(st_c[1]) and abs(st_g[0] - st_c[0]) <= 1e-7
         if want.numel():
             assert float((got - want).abs().max()) < 3e-6, k
-    assert st_c[1] > 0.0
+        if first and st_c[1] > 0.0:
+            started = True
+        elif first:
+            silent_firsts += 1                                     # lead-in silence: gain 0 = "measure again on the next chunk"
+            assert st_g[1] == 0.0 and got.numel() <= p_cpu.window
+    assert st_c[1] > 0.0 and started
+    assert silent_firsts == (1 if cuts == [400, 700, 1000] else 0)
+    # the gain is that of the chunk's AUDIBLE span: lead-in silence in the first chunk does not raise it
+    if cuts == [9000, 31000]:
+        voiced_rms = float(np.sqrt(np.mean(x[2600:9000].astype(np.float64) ** 2)))
+        whole_rms = float(np.sqrt(np.mean(x[:9000].astype(np.float64) ** 2)))
+        g_voiced, g_whole = 10 ** (-23.0 / 20) / voiced_rms, 10 ** (-23.0 / 20) / whole_rms
+        assert abs(st_g[1] / g_voiced - 1.0) < 0.03 and g_whole / g_voiced > 1.15
 
 
 @pytest.mark.parametrize("first,step", [(1, 1), (3, 5), (12, 36), (7, 1000)])
