@@ -731,7 +731,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
 // tap: 7 global loads, 7 barriers and 7 exposed round trips per 32 channels.  Here a workgroup loads the rows its 128 outputs
 // can see - 128 + (taps-1)*dilation of them - ONCE per 32-channel chunk, and the taps are fragment reads at shifted LDS rows:
 // one barrier per `taps` MFMA steps, the next chunk's window in flight during all of them.
-// Requires rows_in == rows_out, tap_offset = -(taps-1)*tap_stride, Cin % 32 == 0, (taps-1)*tap_stride <= 64, split_k = 1.
+// Requires rows_in == rows_out, tap_offset = -(taps-1)*tap_stride, Cin % 32 == 0, (taps-1)*tap_stride <= 63, split_k = 1
+// (the LDS window has 64 rows of halo room; its last row is then never a window row and always holds zeros: the ZERO ROW below).
 // The workgroup tile is (WGM*MT*32) rows: 128 by default; 256 (MT doubled) for the 96- and 192-channel stages, whose four
 // waves all need the SAME weight fragments (the waves split the rows, not the 96 columns) - with 3 workgroups per CU the
 // per-CU vector L1 (64 B/clk) then moves as many weight bytes per tap as the SIMDs spend cycles on its MFMAs; twice the
@@ -744,7 +745,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mid(MidArgs g) {
 // (fragments from L2) and runs that conv's epilogue (bias, residual, the next unit's SnakeBeta planes).  Saved per element:
 // the 4-byte write and the 4-byte re-read of the intermediate planes (24 -> 16 bytes of HBM traffic per element and unit) and
 // one launch.
-template <int WGM, int WGN, int MT, int NTT, bool FUSE = false>
+// TAPS > 0: the tap count is a compile-time constant (7 for every k = 7 conv of the codec decoder) and the tap loop is unrolled -
+// the weight-fragment double buffer then alternates by renaming instead of by 16-24 register copies per tap.  Round 4's counters
+// (SQ_INSTS_VALU against SQ_INSTS_MFMA, profiles/r04_pmc_vocoder_sq.txt) showed 4.5-6 vector instructions per MFMA in these
+// kernels - copies, the zero select of the causal padding, LDS addressing - competing with the MFMAs for the SIMD's issue slots:
+// the matrix pipe sat at 0.3-0.5 while the waves waited to ISSUE (SQ_WAIT_INST_ANY 0.4-0.47 of their cycles), not for memory.
+template <int WGM, int WGN, int MT, int NTT, bool FUSE = false, int TAPS = 0>
 __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win(TiledArgs g) {
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(!FUSE || (WGN == 1 && NTT == 3), "the fused 1x1 conv needs every output channel of a row in one wave");
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
     }
     const int64_t m0 = rt * BMT;
     const int n0 = ct * BNT;
-    const int taps = g.a.taps, stride = g.a.tap_stride, Cin = g.a.Cin;
+    const int taps = TAPS > 0 ? TAPS : g.a.taps, stride = g.a.tap_stride, Cin = g.a.Cin;
     const int halo = (taps - 1) * stride, WR = BMT + halo, n_cc = Cin >> 5;
     const bf16_t* __restrict__ hi = reinterpret_cast<const bf16_t*>(g.a.ptr);
     const bf16_t* __restrict__ lo = reinterpret_cast<const bf16_t*>(g.a.ptr_lo);
@@ -854,7 +860,8 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
         const int buf = cc & 1;
         const bool more = cc + 1 < n_cc;
         if (more) load_win(cc + 1, ra, rl);
-        for (int tap = 0; tap < taps; ++tap) {
+#pragma unroll
+        for (int tap = 0; tap < (TAPS > 0 ? TAPS : taps); ++tap) {
             const bool last = tap + 1 == taps;
             if (!last) load_b(tap + 1, cc, rb_next);
             else if (more) load_b(0, cc + 1, rb_next);
@@ -862,16 +869,14 @@ __global__ __launch_bounds__(256, (WGM * MT * 32 > 128) ? 2 : 3) void k_conv_win
             s8_t fa[MT][2], fl[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int wrow = (wm * MT + mt) * 32 + r + tap * stride;
-                const bool ok = t_row[mt] >= reach;
+                // a tap reaching before the start of its item reads zeros: such a lane reads the window's ZERO ROW instead of its
+                // own row - one select on the row index per sub-tile and tap, where zeroing the loaded fragments took 16 (2
+                // v_cndmask per MFMA: 193 selects against 96 MFMAs in the unrolled block, competing with them for issue slots)
+                const int wrow = t_row[mt] >= reach ? (wm * MT + mt) * 32 + r + tap * stride : WIN_ROWS - 1;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     fa[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * 2 * PLANE + lds_a_off(wrow, kk * 2 + h));
                     fl[mt][kk] = *reinterpret_cast<const s8_t*>(lds + buf * 2 * PLANE + PLANE + lds_a_off(wrow, kk * 2 + h));
-                    if (!ok) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { fa[mt][kk][j] = 0; fl[mt][kk][j] = 0; }
-                    }
                 }
             }
 #pragma unroll
@@ -1012,6 +1017,7 @@ rt_knob g_col_max_rows{64};         // batches up to this many rows decode on th
                                 // launch and the predictor's two-position first pass runs as two 64-row launches: 715 audio-s/s at batch 64 against
                                 // 510 at batch 32 (1.7B, bench.py --batch 64) - every weight byte serves twice the rows for ~1.4x the launch time
 rt_knob g_conv_tall{1};            // 1: 256-row tiles for the k>1 convs of the 96- / 192-channel stages
+rt_knob g_conv_unroll{1};          // 1: k = 7 convs run the tap-unrolled instantiation of k_conv_win (rt_debug_tune 2600 / 2601)
 rt_knob g_conv_win{1};             // 1: k>1 convs on operand planes keep their input window in LDS (k_conv_win)
 rt_knob g_tile96{1};               // 1: 128x96 workgroup tiles for N = 96 / 192 (codec decoder), 0: always 128x128
 rt_knob g_col_split{0};            // 0: automatic (col_split_for), else forced 1 / 2 / 4
@@ -1108,7 +1114,7 @@ rt_knob g_fuse_conv{1};            // 1: a 96-channel k>1 conv and the 1x1 conv 
 // conv's workgroup tile holds every output channel (96 channels, the LDS-window kernel) - else two launches through the planes
 bool conv_pair_fusable(const GemmA& a, const PackedW& w, const GemmEpi& e, const PackedW& w2) {
     return g_fuse_conv && g_conv_win && g_tile96 && w.N == 96 && w2.N == 96 && w2.K == 96 && w2.Kp == 96 && e.act == ACT_SNAKE && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 &&
-           a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out && a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 &&
+           a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out && a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 63 &&
            a.M % a.rows_out == 0;
 }
 
@@ -1129,7 +1135,7 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e,
     const bool narrow = g_tile96 && e.split_k == 1 && w.N % 96 == 0 && w.N % 128 != 0;
     // codec decoder k>1 convs on operand planes: input window in LDS (k_conv_win)
     const bool conv_win = g_conv_win && a.split && !a.is_f32 && a.ptr_lo && a.taps >= 2 && a.Cin % 32 == 0 && a.rows_out > 0 && a.rows_in == a.rows_out &&
-        a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 64 && e.split_k == 1 && a.M % a.rows_out == 0;
+        a.tap_offset == -(a.taps - 1) * a.tap_stride && (a.taps - 1) * a.tap_stride <= 63 && e.split_k == 1 && a.M % a.rows_out == 0;
     const bool tall = conv_win && narrow && (g_conv_tall == 2 || (g_conv_tall == 1 && a.M >= 256 * 1024));   // 256-row tiles (see k_conv_win; 2 = forced, tests)
     const int bm = tall ? 256 : BM;
     const int64_t my = (a.M + bm - 1) / bm;
@@ -1147,14 +1153,19 @@ int launch_gemm(rt_ctx* ctx, const GemmA& a, const PackedW& w, const GemmEpi& e,
             e2->split_k != 1 || e2->ldc < 96)
             return rt_fail(ctx, RT_ERR_INVALID, "gemm: this conv pair cannot be fused (96 channels, k > 1 conv with SnakeBeta, then a 96 x 96 1x1 conv)");
         g.Wp2 = w2->data; g.NT2 = w2->Np / 32; g.KT2 = w2->Kp / 16; g.N2 = w2->N; g.e2 = *e2;
-        if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3, true>), grid, dim3(256), 0, ctx->stream, g);
+        const bool t7f = a.taps == 7 && g_conv_unroll;
+        if (tall && t7f) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3, true, 7>), grid, dim3(256), 0, ctx->stream, g);
+        else if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3, true>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3, true>), grid, dim3(256), 0, ctx->stream, g);
         RT_HIP(ctx, hipGetLastError());
         return RT_OK;
     }
     if (conv_win) {
-        if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3>), grid, dim3(256), 0, ctx->stream, g);
+        const bool t7 = a.taps == 7 && g_conv_unroll;
+        if (tall && t7) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3, false, 7>), grid, dim3(256), 0, ctx->stream, g);
+        else if (tall) hipLaunchKernelGGL((k_conv_win<4, 1, 2, 3>), grid, dim3(256), 0, ctx->stream, g);
         else if (narrow) hipLaunchKernelGGL((k_conv_win<4, 1, 1, 3>), grid, dim3(256), 0, ctx->stream, g);
+        else if (t7) hipLaunchKernelGGL((k_conv_win<2, 2, 2, 2, false, 7>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((k_conv_win<2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);
         RT_HIP(ctx, hipGetLastError());
         return RT_OK;

@@ -93,6 +93,7 @@ extern rt_knob g_conv_tall;
 extern rt_knob g_col_max_rows;
 extern rt_knob g_tile96;
 extern rt_knob g_conv_win;
+extern rt_knob g_conv_unroll;         // 1: tap-unrolled k = 7 conv kernels
 extern rt_knob g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
 extern rt_knob g_xcd_order;
 extern rt_knob g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
