@@ -288,15 +288,29 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
             if (!e.bias) c_bias[nt] = 0.f;
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        // element i of the accumulator sits (i & 3) + 8 * (i >> 2) rows below element 0
+#define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
+        // Byte offsets of the sub-tile's 16 rows from the tile corner, computed ONCE per 32-row sub-tile for 4-byte and 2-byte
+        // elements; a column tile further right and every store kind (f32, bf16, the hi / lo planes, the second output) then differ by
+        // a compile-time constant that the buffer instruction carries in its immediate offset.  Computed per store - as
+        // (lo0 + RT_ROW(i) * ldc) * bytes for every column tile and every kind - the addressing was 27 vector instructions per 16
+        // stores, ~7 of the ~25 per output element in kernels whose epilogue, not their K loop, sets the pace (round 4).
+        unsigned ro4[16], ro2[16];
+        {
+            const unsigned base = (unsigned)(((row_blk0 + mt) * 32 + 4 * h) * ldc32 + wn * NTT * 32 + r);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned el = base + RT_ROW(i) * ldc32;
+                ro4[i] = el * 4u;
+                ro2[i] = el * 2u;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NTT; ++nt) {
             const int n = n0 + (wn * NTT + nt) * 32 + r;
             if (n >= N) continue;
-            // element i of the accumulator sits (i & 3) + 8 * (i >> 2) rows below element 0
-#define RT_ROW(i) ((i & 3) + 8 * (i >> 2))
-            const unsigned lo0 = (unsigned)(((row_blk0 + mt) * 32 + 4 * h) * ldc32 + (wn * NTT + nt) * 32 + r);   // element offset of element 0 from the corner
-#define RT_OFF(i, bytes) ((lo0 + RT_ROW(i) * ldc32) * (bytes))
+#define RT_OFF(i, bytes) ((bytes) == 4 ? ro4[i] + (unsigned)(nt * 128) : ro2[i] + (unsigned)(nt * 64))
             if (e.split_k > 1) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) buf_st_f32(r_f32, RT_OFF(i, 4), acc[mt][nt][i]);
@@ -384,8 +398,9 @@ __device__ __forceinline__ void tile_epilogue_e(const GemmEpi& e, int64_t M, int
                 }
             }
 #undef RT_OFF
-#undef RT_ROW
         }
+#undef RT_ROW
+    }
 }
 
 // SPLIT: the f32 A operand is fed as two bf16 planes, hi = bf16(x) and lo = bf16(x - hi), and every B fragment
