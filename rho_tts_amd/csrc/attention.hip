@@ -193,8 +193,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += qr[r][j] * kf[j];
-#pragma unroll
-                for (int o = 1; o < LPP; o <<= 1) s += __shfl_xor(s, o, 64);
+                s = group_sum_f32<LPP>(s);          // (DPP: no LDS round trips - common.h)
                 if (p <= hi) {   // uniform within the LPP-lane group
                     const float mn = fmaxf(m[r], s);
                     const float corr = __expf(m[r] - mn), pe = __expf(s - mn);

@@ -308,8 +308,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
                         float s = 0.f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) s += qr[r][j] * kf2[j];
-#pragma unroll
-                        for (int o = 1; o < LPP; o <<= 1) s += __shfl_xor(s, o, 64);
+                        s = group_sum_f32<LPP>(s);  // (DPP: no LDS round trips - common.h)
                         if (p <= hi) {                       // uniform within the 16-lane group
                             const float mn = fmaxf(m[r], s);
                             const float c1 = __expf(m[r] - mn), pe = __expf(s - mn);

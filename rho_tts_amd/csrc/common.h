@@ -83,6 +83,25 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over aligned groups of G = 2, 4, 8 or 16 lanes (every lane of the group gets the total), by DPP modifiers on the adds instead of
+// __shfl_xor: hipcc lowers __shfl_xor to ds_bpermute_b32 - an LDS-crossbar round trip with an `s_waitcnt lgkmcnt(0)` behind each of
+// the log2(G) DEPENDENT steps (~100 cycles apiece) - where a DPP operand costs nothing beyond the add.  Pairings: xor 1 and xor 2 are
+// quad permutations; for xor 4 / xor 8 the row is mirrored within halves / as a whole (lane i <-> 7 - i / 15 - i) - a different lane
+// than i ^ 4 / i ^ 8, but one that holds the SAME value at that step (after the earlier steps every lane of a quad / half holds the
+// quad's / half's total), so the sums are bit-identical to the xor butterfly in ascending order.  All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int G>
+__device__ __forceinline__ float group_sum_f32(float v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "aligned lane groups within a DPP row");
+    if (G >= 2) v += dpp_lane_f32<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+    if (G >= 4) v += dpp_lane_f32<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+    if (G >= 8) v += dpp_lane_f32<0x141>(v);    // row_half_mirror
+    if (G >= 16) v += dpp_lane_f32<0x140>(v);   // row_mirror
+    return v;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -180,8 +180,7 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
                 const float* p = g.rowsq + (int64_t)row * g.rowsq_n;
                 for (int j = RQ_MAX + r; j < g.rowsq_n; j += 16) s += p[j];
             }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = group_sum_f32<16>(s);             // (DPP adds, no LDS round trips: common.h)
             if (r == 0 && row_i < 16 * MT) sh_inv[row_i] = rsqrtf(s / (float)g.K + g.eps);
         }
     }
@@ -262,8 +261,9 @@ __global__ __launch_bounds__(512, (((EPI == COL_SILU && MT == 2) || MT == 1) && 
                 if (g.next_bf16) g.next_bf16[o] = f32_to_bf16(e_nw * xn);   // operand of the GEMM behind the next RMSNorm
             }
             float sq = xn * xn;                   // a 16-lane group = one row's 16 columns
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            // (DPP adds: the four dependent ds_bpermute round trips of a __shfl_xor butterfly sat in the tail of every RESID launch -
+            //  two per layer - between the last store of x and the store of its sums of squares)
+            sq = group_sum_f32<16>(sq);
             if ((e_l & 15) == 0 && e_row < g.M) g.rowsq_out[(int64_t)(g.row_off + e_row) * g.rowsq_out_n + blockIdx.x] = sq;
         } else {                                  // COL_SILU: gate = tile nt, up = tile nt + offset
             if (ok) {
