@@ -26,7 +26,10 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                                                    float* __restrict__ out_f32, int slot_base) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
-    constexpr int U = 4;              // positions in flight per lane
+    // positions in flight per lane.  (8 - a talker row's whole ~500-position context in ONE batch requested before the prologue,
+    // so that no second round trip is exposed - needs 64 registers for K / V alone: 100 spilled registers under the 128 a
+    // 1024-thread workgroup may hold, 17.0 us against 10.7; measured in round 4.)
+    constexpr int U = 4;
     __shared__ float sh[NW][REP][LPP][10];     // NW waves split the cached positions of one (row, kv head)
     __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
     __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][FUSED ? D : 8];   // the appended K / V row (as rounded for the cache)
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 if (nw) {
                     float wa = pwa, wb = pwb;
                     if (!first && act) { wa = nw[lane]; wb = nw[lane + half]; }
-                    const float ss = wave_sum_f32(act ? a * a + b * b : 0.f);
+                    const float ss = wave_sum_rows_f32(act ? a * a + b * b : 0.f);      // (wave-uniform: the vector loop is per wave)
                     const float inv = rsqrtf(ss / (float)D + eps);
                     if (act) { a = wa * (a * inv); b = wb * (b * inv); }
                 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_prefix_mfma(MfmaAttnArgs g) {
             if (is_q || is_k) {
                 const float* nw = is_q ? g.qw : g.kw;
                 if (nw) {
-                    const float ss = wave_sum_f32(a * a + b * b);
+                    const float ss = wave_sum_rows_f32(a * a + b * b);
                     const float inv = rsqrtf(ss / (float)D + g.eps);
                     a = pro_wa * (a * inv); b = pro_wb * (b * inv);
                 }

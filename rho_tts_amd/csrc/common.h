@@ -102,6 +102,15 @@ __device__ __forceinline__ float group_sum_f32(float v) {
     if (G >= 16) v += dpp_lane_f32<0x140>(v);   // row_mirror
     return v;
 }
+// Whole-wave sum on every lane without LDS round trips: DPP adds inside the four 16-lane rows, then the four row totals through
+// v_readlane (scalar registers).  Six dependent ds_bpermute steps of wave_sum_f32 are ~0.3 us on a launch's critical path; this is
+// four DPP adds and four readlanes.  ALL 64 lanes must be active (wave-uniform call sites only); the association differs from
+// wave_sum_f32's (rows first), so the two are not interchangeable where another kernel must reproduce the bits.
+__device__ __forceinline__ float wave_sum_rows_f32(float v) {
+    const int x = __float_as_int(group_sum_f32<16>(v));
+    return (__int_as_float(__builtin_amdgcn_readlane(x, 0)) + __int_as_float(__builtin_amdgcn_readlane(x, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(x, 32)) + __int_as_float(__builtin_amdgcn_readlane(x, 48)));
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64) void k_qkv_post(const float* __restrict__ slabs
     if (is_q || is_k) {
         const float* nw = is_q ? qw : kw;
         if (nw) {
-            const float ss = wave_sum_f32(act ? a * a + b * b : 0.f);
+            const float ss = wave_sum_rows_f32(act ? a * a + b * b : 0.f);   // (same association as the fused attention prologue)
             const float inv = rsqrtf(ss / (float)d + eps);
             if (act) { a = nw[lane] * (a * inv); b = nw[lane + half] * (b * inv); }
         }
