@@ -111,6 +111,43 @@ __device__ __forceinline__ float wave_sum_rows_f32(float v) {
     return (__int_as_float(__builtin_amdgcn_readlane(x, 0)) + __int_as_float(__builtin_amdgcn_readlane(x, 16))) +
            (__int_as_float(__builtin_amdgcn_readlane(x, 32)) + __int_as_float(__builtin_amdgcn_readlane(x, 48)));
 }
+// The same for order-independent integer / max reductions of the sampler (results equal the shuffle forms bit for bit).
+template <int CTRL, bool ZERO_FILL = false>
+__device__ __forceinline__ int dpp_lane_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, ZERO_FILL); }
+template <int G>
+__device__ __forceinline__ int group_sum_i32(int v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "aligned lane groups within a DPP row");
+    if (G >= 2) v += dpp_lane_i32<0xB1>(v);
+    if (G >= 4) v += dpp_lane_i32<0x4E>(v);
+    if (G >= 8) v += dpp_lane_i32<0x141>(v);
+    if (G >= 16) v += dpp_lane_i32<0x140>(v);
+    return v;
+}
+// Largest value of the wave on every lane (`a > b ? a : b` at every step, as the shuffle form it replaces).  All lanes active.
+__device__ __forceinline__ float wave_max_rows_f32(float v) {
+    float o;
+    o = dpp_lane_f32<0xB1>(v);  v = o > v ? o : v;
+    o = dpp_lane_f32<0x4E>(v);  v = o > v ? o : v;
+    o = dpp_lane_f32<0x141>(v); v = o > v ? o : v;
+    o = dpp_lane_f32<0x140>(v); v = o > v ? o : v;
+    const int x = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    const float a = r1 > r0 ? r1 : r0, b = r3 > r2 ? r3 : r2;
+    return b > a ? b : a;
+}
+// Inclusive prefix sum over the 64 lanes: Hillis-Steele inside the 16-lane rows by row_shr (zero fill), then the totals of the
+// rows below through v_readlane.  All lanes active.
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned u) {
+    int v = (int)u;
+    v += dpp_lane_i32<0x111, true>(v);          // row_shr:1
+    v += dpp_lane_i32<0x112, true>(v);          // row_shr:2
+    v += dpp_lane_i32<0x114, true>(v);          // row_shr:4
+    v += dpp_lane_i32<0x118, true>(v);          // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (int)(threadIdx.x & 63) >> 4;
+    return (unsigned)(v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0));
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -419,7 +419,8 @@ int rt_gen_run::enqueue_a(Lane& ln) {
             RT_TRY(gemm_rows(m, ln.hn, n, PW(m, "pred.mtp"), ln.logits, &ns));
             RT_TRY(launch_reduce_slabs(ctx, ln.logits, ns, n, Hp, VEC(m, "pred.mtp_b"), ACT_NONE, ln.xp, nullptr));
         }
-        RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, codes, n, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
+        // (column path: the embedding rows of code 0 are gathered by the rowsq launch below - one launch less per frame)
+        if (!col) RT_TRY(launch_gather_f32(ctx, m->proj_c0, Hp, codes, n, ln.xp + (size_t)n * Hp, nullptr, G, ln.d_frame, codes_fs));
     } else {
         // equal-width predictor: its first input row is the talker's normalised hidden state itself
         if (col) RT_TRY(launch_norm_tiled_rows(ctx, ln.dwt.xT, ln.rowsq_t, NTt, m->talker.norm, c.talker.rms_eps, n, H, ln.xp));
@@ -428,7 +429,9 @@ int rt_gen_run::enqueue_a(Lane& ln) {
     }
     m->prof_class = 1;
     if (col) {
-        RT_TRY(launch_rowsq(ctx, ln.xp, n2, Hp, ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1));
+        RowsqGather gt;
+        if (m->has_mtp()) { gt.table = m->proj_c0; gt.idx = codes; gt.idx_stride = G; gt.first = n; gt.frame_ptr = ln.d_frame; gt.idx_frame_stride = codes_fs; }
+        RT_TRY(launch_rowsq(ctx, ln.xp, n2, Hp, ln.rowsq_p, NTp, ln.dwp.xT, ln.dwp.xa, m->pred.L[0].ln1, nullptr, nullptr, &gt));
         RT_TRY(stack_decode(m, m->pred, ln.dwp, ln.dwp.xT, ln.rowsq_p, n2, ln.d_slot_b, ln.d_pos_p2, 0, false));
     } else {
         RT_TRY(stack_forward(m, m->pred, ln.wp, ln.xp, n2, ln.d_slot_b, ln.d_pos_p2, 0, ln.hn_p, nullptr));

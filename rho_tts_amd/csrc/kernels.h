@@ -142,9 +142,18 @@ struct ColArgs {
 int launch_gemm_col(rt_ctx* ctx, const ColArgs& a, const PackedW& w, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // rowsq[M][0] = sum_k x[m][k]^2  (seed of the first NORM prologue of a stack)
 // src_rows / dst_rows (device, [M], optional): block i reads x row src_rows[i] and writes (tiled / rowsq) row dst_rows[i]
+// gather (optional): rows first..M-1 are read from table[idx[(row - first) * idx_stride]] (f32 rows of width H) instead of x; the
+// index array moves by idx_frame_stride per frame of *frame_ptr - launch_gather_f32 folded into this launch
+struct RowsqGather {
+    const float* table = nullptr;
+    const int32_t* idx = nullptr;
+    int idx_stride = 1, first = 0;
+    const int32_t* frame_ptr = nullptr;
+    int64_t idx_frame_stride = 0;
+};
 int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled = nullptr,
                  bf16_t* a_tiled = nullptr, const float* norm_w = nullptr, const int32_t* src_rows = nullptr,
-                 const int32_t* dst_rows = nullptr);
+                 const int32_t* dst_rows = nullptr, const RowsqGather* gather = nullptr);
 
 // decode-step input: x = add_vec + sum of n_src (<= 16) bf16 embedding rows (or one row of f32_table), emitted as tiled x,
 // tiled bf16(norm_w .* x) and rowsq - the fusion of launch_gather_sum / launch_gather_f32 with launch_rowsq

@@ -147,14 +147,23 @@ __global__ __launch_bounds__(256) void k_add_rmsnorm_v(float* __restrict__ x, co
 __global__ __launch_bounds__(256) void k_rowsq(const float* __restrict__ x, int H, float* __restrict__ rowsq, int rowsq_n,
                                                float* __restrict__ x_tiled, bf16_t* __restrict__ a_tiled,
                                                const float* __restrict__ norm_w, const int32_t* __restrict__ src_rows,
-                                               const int32_t* __restrict__ dst_rows) {
+                                               const int32_t* __restrict__ dst_rows, RowsqGather gt) {
     __shared__ float sh[4];
     // (optional row maps: block i reads row src_rows[i] of x and writes decode row dst_rows[i] - a queued item taking over a row)
     const int64_t row = dst_rows ? dst_rows[blockIdx.x] : blockIdx.x;
     const f4_t* xr = reinterpret_cast<const f4_t*>(x + (int64_t)(src_rows ? src_rows[blockIdx.x] : blockIdx.x) * H);
+    // (optional gather: blocks from gt.first on read row idx[block - first] of an f32 table instead - the predictor's first pass,
+    //  whose second half of rows are embeddings of the code just sampled: the same loop and sums as k_gather_f32 + this kernel)
+    bool zero_row = false;                               // (a negative index is a row of zeros, as in k_gather_f32)
+    if (gt.table && (int)blockIdx.x >= gt.first) {
+        const int32_t* ix = gt.idx + (gt.frame_ptr ? (int64_t)(*gt.frame_ptr) * gt.idx_frame_stride : 0);
+        const int id = ix[(int64_t)((int)blockIdx.x - gt.first) * gt.idx_stride];
+        zero_row = id < 0;
+        xr = reinterpret_cast<const f4_t*>(gt.table + (int64_t)(id < 0 ? 0 : id) * H);
+    }
     float ss = 0.f;
     for (int i = threadIdx.x; i < (H >> 2); i += 256) {
-        const f4_t v = xr[i];
+        const f4_t v = zero_row ? f4_t{0.f, 0.f, 0.f, 0.f} : xr[i];
         ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         if (x_tiled) *reinterpret_cast<f4_t*>(x_tiled + tile_off((int)row, i * 4, H)) = v;
         if (a_tiled) {   // bf16(norm_w .* x): the first GEMM's operand (its row scale is applied after the product)
@@ -516,9 +525,12 @@ int launch_add_rmsnorm(rt_ctx* ctx, float* x, int M, int H, const float* slabs, 
 }
 
 int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int rowsq_n, float* x_tiled, bf16_t* a_tiled,
-                 const float* norm_w, const int32_t* src_rows, const int32_t* dst_rows) {
+                 const float* norm_w, const int32_t* src_rows, const int32_t* dst_rows, const RowsqGather* gather) {
     if (M <= 0) return RT_OK;
-    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w, src_rows, dst_rows);
+    const RowsqGather gt = gather ? *gather : RowsqGather{};
+    if (gt.table && (src_rows || dst_rows || gt.first < 0 || gt.first > M || !gt.idx))
+        return rt_fail(ctx, RT_ERR_INVALID, "rowsq: gathered rows take no row maps (first %d of %d rows)", gt.first, M);
+    hipLaunchKernelGGL(k_rowsq, dim3(M), dim3(256), 0, ctx->stream, x, H, rowsq, rowsq_n, x_tiled, a_tiled, norm_w, src_rows, dst_rows, gt);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

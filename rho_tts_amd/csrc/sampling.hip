@@ -330,8 +330,7 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
         float mloc = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NV; ++j) mloc = (valid[j] && v[j] > mloc) ? v[j] : mloc;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(mloc, o, 64); mloc = ov > mloc ? ov : mloc; }
+        mloc = wave_max_rows_f32(mloc);              // (DPP + readlane: no LDS round trips, common.h)
         if (lane == 0) sh_f[w] = mloc;
         for (int i = tid; i < 1024; i += NT) hist[i] = 0u;
         if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; wcnt[0] = 0; }
@@ -356,9 +355,7 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
                 c16[4 * q] = h4.x; c16[4 * q + 1] = h4.y; c16[4 * q + 2] = h4.z; c16[4 * q + 3] = h4.w;
                 sum += h4.x + h4.y + h4.z + h4.w;
             }
-            unsigned incl = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            const unsigned incl = wave_scan_incl_u32(sum);
             unsigned run = incl - sum;
             if (run < (unsigned)kf && incl >= (unsigned)kf) {           // exactly one lane: the running count reaches k inside its 16 bins
                 int bs = 0;
@@ -468,7 +465,11 @@ __global__ __launch_bounds__(NW * 64) void k_sample_w(SampleArgs A) {
                 rank += (o0 > my ? 1 : 0) + (o1 > my ? 1 : 0) + (o2 > my ? 1 : 0) + (o3 > my ? 1 : 0);
             }
             for (; j < n_c; j += G) rank += ckey[j] > my ? 1 : 0;
-            for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (G == 16) rank = group_sum_i32<16>(rank);
+            else if (G == 8) rank = group_sum_i32<8>(rank);                  // (integer sums by DPP adds - every lane runs this; common.h)
+            else if (G == 4) rank = group_sum_i32<4>(rank);
+            else if (G == 2) rank = group_sum_i32<2>(rank);
+            else for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
             if (part == 0 && c < n_c && rank < kf) sorted[rank] = my;
         }
         if (A.stamps && row == 0 && tid == 0) A.stamps[4] = wall_clock64();
