@@ -238,12 +238,12 @@ int rt_gen_run::init(const rt_generate_args* a) {
         RT_TRY(pool_arr(m, n2, &ln.d_zero_pos));
         RT_TRY(pool_arr(m, n, &ln.d_items));
         RT_TRY(pool_arr(m, (size_t)n * Vc, &ln.d_seen));
-        RT_TRY(pool_arr(m, 1, &ln.d_frame));
+        RT_TRY(pool_arr(m, 2, &ln.d_frame));                      // [0] the frame counter, [1] arrivals of the launch that advances it
         RT_TRY(pool_arr(m, n, &ln.d_frame_off));
         RT_HIP(ctx, hipMemsetAsync(ln.d_frame_off, 0, n * 4, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(ln.d_seen, 0, (size_t)n * Vc, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(ln.d_zero_pos, 0, n2 * 4, ctx->stream));
-        RT_HIP(ctx, hipMemsetAsync(ln.d_frame, 0, 4, ctx->stream));
+        RT_HIP(ctx, hipMemsetAsync(ln.d_frame, 0, 8, ctx->stream));
         std::vector<int32_t> sl(n2), p2(n2);
         for (int b = 0; b < n; ++b) { sl[b] = ln.b0 + b; sl[n + b] = ln.b0 + b; p2[b] = 0; p2[n + b] = 1; }
         RT_HIP(ctx, hipMemcpyAsync(ln.d_slot_b, sl.data(), n2 * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -488,23 +488,27 @@ int rt_gen_run::enqueue_a(Lane& ln) {
 int rt_gen_run::enqueue_b(Lane& ln) {
     const int n = ln.n;
     int32_t* codes = d_codes + (size_t)ln.b0 * G;
+    // (rt_debug_tune 2701, off by default - see the end of this function) frame += 1 by the last workgroup of the talker-input
+    // launch once every workgroup has read the counter (rowops.hip); the talker step behind it then sees frame + 1 and takes its
+    // positions with pos_add = -1
+    const bool inc_early = col && G <= 16 && g_frame_inc_fold;
     if (col && G <= 16) {
         RT_TRY(launch_embed_rowsq(ctx, m->d_frame_srcs, G, nullptr, codes, G, ln.d_frame, codes_fs, n, H, pad_t, ln.rowsq_t, NTt, ln.dwt.xT,
-                                  ln.dwt.xa, m->talker.L[0].ln1));
+                                  ln.dwt.xa, m->talker.L[0].ln1, inc_early ? ln.d_frame : nullptr,
+                                  inc_early ? reinterpret_cast<unsigned*>(ln.d_frame + 1) : nullptr));
     } else {
         RT_TRY(launch_gather_sum(ctx, m->d_frame_srcs, G, codes, n, H, pad_t, nullptr, nullptr, ln.xt, nullptr, G, ln.d_frame, codes_fs));
         if (col) RT_TRY(launch_rowsq(ctx, ln.xt, n, H, ln.rowsq_t, NTt, ln.dwt.xT, ln.dwt.xa, m->talker.L[0].ln1));
     }
     if (col) {
-        RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, 0, true, ln.d_frame));
+        RT_TRY(stack_decode(m, m->talker, ln.dwt, ln.dwt.xT, ln.rowsq_t, n, ln.d_slot_b, ln.d_pos_b, inc_early ? -1 : 0, true, ln.d_frame));
     } else {
         RT_TRY(stack_forward(m, m->talker, ln.wt, ln.xt, n, ln.d_slot_b, ln.d_pos_b, 0, ln.hn, ln.hn_f32, ln.d_frame));
     }
-    // frame += 1 stays a launch of its own.  Letting the talker step's last GEMM launch advance the counter (one thread of a launch
-    // that does not read it; round 4) measured SLOWER, not faster: 204.56 / 203.23 ms per step folded against 203.98 / 202.65 with
-    // this 3.9-us launch, A/B on one box - the extra kernel argument and tail branch cost each of the 18 764 GEMM launches of a
-    // step more than the 44 launches saved.
-    hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, ln.d_frame);
+    // frame += 1 stays a launch of its own: BOTH ways of folding it into a neighbour measured slower, A/B on one box each (round 4,
+    // DESIGN.md section 6) - the talker step's last GEMM launch advancing it (204.56 / 203.23 ms per step against 203.98 / 202.65),
+    // and the talker-input launch advancing it by its last workgroup (rt_debug_tune 2701: 198.04 / 197.36 against 196.20 / 196.35).
+    if (!inc_early)     hipLaunchKernelGGL(k_frame_inc, dim3(1), dim3(64), 0, ctx->stream, ln.d_frame);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -97,6 +97,7 @@ extern rt_knob g_conv_unroll;         // 1: tap-unrolled k = 7 conv kernels
 extern rt_knob g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
 extern rt_knob g_xcd_order;
 extern rt_knob g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
+extern rt_knob g_frame_inc_fold;       // 1: the talker-input launch of a frame advances the frame counter (no k_frame_inc launch)
 extern rt_knob g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
 extern rt_knob g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
 extern rt_knob g_col_split;           // 0: automatic sub-tile split of narrow decode GEMMs, 1/2/4: forced
@@ -160,7 +161,8 @@ int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int ro
 struct GatherSrc;
 int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const float* f32_table, const int32_t* d_idx, int idx_stride,
                        const int32_t* frame_ptr, int64_t idx_frame_stride, int M, int H, const float* add_vec, float* rowsq, int rowsq_n,
-                       float* x_tiled, bf16_t* a_tiled, const float* norm_w);
+                       float* x_tiled, bf16_t* a_tiled, const float* norm_w, int32_t* frame_inc = nullptr, unsigned* arrive = nullptr);
+// (frame_inc == frame_ptr, arrive = a zeroed device counter: the last workgroup of the launch also advances the frame counter)
 
 // out[M][H] (row-major f32) = norm_w .* x * inv_rms(row) from the column path's tiled x and its rowsq partials
 int launch_norm_tiled_rows(rt_ctx* ctx, const float* x_tiled, const float* rowsq, int rowsq_n, const float* w, float eps, int M, int H,

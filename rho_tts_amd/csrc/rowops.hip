@@ -187,12 +187,14 @@ __global__ __launch_bounds__(256) void k_embed_rowsq(const GatherSrc* __restrict
                                                      const int32_t* __restrict__ frame_ptr, int64_t idx_frame_stride, int H,
                                                      const float* __restrict__ add_vec, float* __restrict__ rowsq, int rowsq_n,
                                                      float* __restrict__ x_tiled, bf16_t* __restrict__ a_tiled,
-                                                     const float* __restrict__ norm_w) {
+                                                     const float* __restrict__ norm_w, int32_t* frame_inc, unsigned* arrive) {
     constexpr int MAXS = 16;
     __shared__ const bf16_t* sh_tab[MAXS];
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
-    if (frame_ptr) idx += (int64_t)(*frame_ptr) * idx_frame_stride;
+    // (frame_inc: this launch also advances the frame counter it reads - see below; the counter is then read with an atomic load,
+    //  which the compiler may neither duplicate nor re-issue behind the barrier)
+    if (frame_ptr) idx += (int64_t)(frame_inc ? __atomic_load_n(frame_ptr, __ATOMIC_RELAXED) : *frame_ptr) * idx_frame_stride;
     if (tid < MAXS) {
         const bf16_t* p = nullptr;
         if (tid < n_src) {
@@ -203,6 +205,14 @@ __global__ __launch_bounds__(256) void k_embed_rowsq(const GatherSrc* __restrict
     }
     const int fid = f32_table ? idx[(int64_t)row * idx_stride] : -1;
     __syncthreads();
+    // frame += 1 by the LAST workgroup to get here (instead of a launch of its own, k_frame_inc).  The only readers of the counter
+    // in this launch are the lanes that filled sh_tab: their index loads - which needed the counter - had to return before the
+    // table pointers could be written, i.e. before the barrier above, so once every workgroup has arrived nobody reads it again.
+    // (frame_inc is refused together with f32_table, whose index load is not tied to the barrier that way.)
+    if (frame_inc && tid == 0 && atomicAdd(arrive, 1u) == gridDim.x - 1) {
+        *arrive = 0u;
+        atomicAdd(frame_inc, 1);
+    }
     float ss = 0.f;
     for (int c = tid * 8; c < H; c += 2048) {
         uint4 raw[MAXS];
@@ -537,12 +547,14 @@ int launch_rowsq(rt_ctx* ctx, const float* x, int M, int H, float* rowsq, int ro
 
 int launch_embed_rowsq(rt_ctx* ctx, const GatherSrc* d_srcs, int n_src, const float* f32_table, const int32_t* d_idx, int idx_stride,
                        const int32_t* frame_ptr, int64_t idx_frame_stride, int M, int H, const float* add_vec, float* rowsq, int rowsq_n,
-                       float* x_tiled, bf16_t* a_tiled, const float* norm_w) {
+                       float* x_tiled, bf16_t* a_tiled, const float* norm_w, int32_t* frame_inc, unsigned* arrive) {
     if (M <= 0) return RT_OK;
     if (n_src > 16 || H % 8 || !x_tiled || !a_tiled || !norm_w || !rowsq || rowsq_n < 1 || (n_src > 0 && !d_srcs))
         return rt_fail(ctx, RT_ERR_INVALID, "embed_rowsq: n_src %d (<= 16), H %d (multiple of 8) or a missing buffer", n_src, H);
+    if (frame_inc && (f32_table || !arrive || frame_inc != frame_ptr))
+        return rt_fail(ctx, RT_ERR_INVALID, "embed_rowsq: the frame counter is advanced by launches over bf16 sources only, with an arrival counter");
     hipLaunchKernelGGL(k_embed_rowsq, dim3(M), dim3(256), 0, ctx->stream, d_srcs, n_src, f32_table, d_idx, idx_stride, frame_ptr,
-                       idx_frame_stride, H, add_vec, rowsq, rowsq_n, x_tiled, a_tiled, norm_w);
+                       idx_frame_stride, H, add_vec, rowsq, rowsq_n, x_tiled, a_tiled, norm_w, frame_inc, arrive);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -219,6 +219,14 @@ def test_decode_lanes_and_tile_split_do_not_change_results(ctx):
         assert all(torch.equal(a, b) for a, b in zip(base, sep))
         for key in ("talker", "predictor"):
             assert torch.equal(tr0[key], tr_sep[key])
+        try:        # frame counter advanced by the talker-input launch's last workgroup (2701) == by its own launch (2700, default)
+            lib.rt_debug_tune(2701, 0)
+            inc, tr_inc = nm.generate(texts, frames, sp, seed=77, trace=True)
+        finally:
+            lib.rt_debug_tune(2700, 0)
+        assert all(torch.equal(a, b) for a, b in zip(base, inc))
+        for key in ("talker", "predictor"):
+            assert torch.equal(tr0[key], tr_inc[key])
         outs = {}
         try:
             for code in (501, 502, 504):
