@@ -97,7 +97,8 @@ RT_API int rt_debug_sample(rt_ctx* ctx, const float* d_logits, int32_t M, int32_
  *   2300/2301 decode GEMMs of <= 16 rows on the 32-row / the two-workgroups-per-CU 16-row instantiation |
  *   2400/2401 gate/up decode GEMM whose tile pairs are 1.5x the CUs: one pair per workgroup (1.5 rounds) / 1.5 pairs per workgroup (one round) |
  *   2600/2601 the codec decoder's k = 7 convs on the generic / the tap-unrolled instantiation of k_conv_win |
- *   2700/2701 the decode frame counter advanced by a launch of its own / by the last workgroup of the frame's talker-input launch
+ *   2700/2701 the decode frame counter advanced by a launch of its own / by the last workgroup of the frame's talker-input launch |
+ *   2800/2801 the predictor's two-position first pass: q/k norm + RoPE + append as a launch of its own in front of the attention / inside the fused attention
  * The rt_bench_* entry points are the microbenchmarks behind tools/bench_*.py (for rt_bench_gemm_col choose
  * n_mats * N * K * 2 bytes > 512 MB to stream from HBM, not from cache). */
 RT_API int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu);

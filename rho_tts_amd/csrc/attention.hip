@@ -23,7 +23,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                                                    const float* __restrict__ kw, float eps, const float* __restrict__ cosT,
                                                    const float* __restrict__ sinT, const int32_t* __restrict__ frame_ptr, int out_tiled, int prefix_slot,
                                                    int prefix_len, const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vc_lo,
-                                                   float* __restrict__ out_f32, int slot_base) {
+                                                   float* __restrict__ out_f32, int slot_base, int pair_n) {
     constexpr int LPP = D / 8;        // lanes per cached position
     constexpr int PPW = 64 / LPP;     // positions per wave step
     // positions in flight per lane.  (8 - a talker row's whole ~500-position context in ONE batch requested before the prologue,
@@ -33,6 +33,11 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     __shared__ float sh[NW][REP][LPP][10];     // NW waves split the cached positions of one (row, kv head)
     __shared__ float sh_q[FUSED ? REP : 1][FUSED ? D : 1];
     __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][FUSED ? D : 8];   // the appended K / V row (as rounded for the cache)
+    // pair_n > 0 (FUSED; the predictor's two-position first pass): rows >= pair_n sit ONE position behind row - pair_n of the same
+    // slot, which this very launch appends.  Such a workgroup cannot read that position from the cache (another workgroup is
+    // writing it), so it works out the partner's K / V itself - the same operations on the same operands, i.e. the bits the
+    // cache will hold - keeps them here, and patches them over the cache read.  Replaces a k_qkv_post launch per layer.
+    __shared__ __attribute__((aligned(16))) bf16_t sh_kv2[2][FUSED ? D : 8];
 
     // x = kv head (fastest): workgroups are dealt round-robin over the 8 XCDs, so with 8 kv heads every XCD's L2 holds
     // ONE head's shared-prefix K/V and serves it to all the rows of that head
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     int lo = 0;
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
     const float scale = rsqrtf((float)D);
+    const bool partner = FUSED && pair_n > 0 && row >= pair_n;
     const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
     const bf16_t* kb = kc + base * D + sub * 8;
     const bf16_t* vb = vc + base * D + sub * 8;
@@ -103,12 +109,14 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 
     if (FUSED) {
         // vectors of this head group: REP query heads, then K, then V; wave w takes vectors w, w+4, ...
-        for (int vec = w; vec < REP + 2; vec += NW) {
-            const bool is_q = vec < REP, is_k = vec == REP;
+        for (int vec = w; vec < REP + 2 + (partner ? 2 : 0); vec += NW) {
+            const bool mate = vec >= REP + 2;        // K / V of the partner row (one position earlier), for this workgroup only
+            const bool is_q = vec < REP, is_k = vec == REP || vec == REP + 2;
             const int col0 = is_q ? (kh * REP + vec) * D : (is_k ? (heads + kh) * D : (heads + kv_heads + kh) * D);
-            const bool first = vec == w;             // (operands of the first vector are already on their way, see the top)
+            const bool first = vec == w && !mate;    // (operands of the first vector are already on their way, see the top)
+            const int vrow = mate ? row - pair_n : row, vpos = mate ? hi - 1 : hi;
             float a = pa, b = pb;
-            if (!first && act) { a = q[(int64_t)row * width + col0 + lane]; b = q[(int64_t)row * width + col0 + lane + half]; }
+            if (!first && act) { a = q[(int64_t)vrow * width + col0 + lane]; b = q[(int64_t)vrow * width + col0 + lane + half]; }
             if (is_q || is_k) {
                 const float* nw = is_q ? qw : kw;
                 if (nw) {
@@ -120,14 +128,17 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 }
                 if (act) {
                     float c = pc, s = psn;
-                    if (!first) { c = cosT[(int64_t)hi * half + lane]; s = sinT[(int64_t)hi * half + lane]; }
+                    if (!first) { c = cosT[(int64_t)vpos * half + lane]; s = sinT[(int64_t)vpos * half + lane]; }
                     const float ra = a * c - b * s, rb = b * c + a * s;
                     a = ra; b = rb;
                 }
             }
             if (act) {
                 if (is_q) { sh_q[FUSED ? vec : 0][FUSED ? lane : 0] = a; sh_q[FUSED ? vec : 0][FUSED ? lane + half : 0] = b; }
-                else {
+                else if (mate) {                      // (the partner's own workgroup writes these to the cache)
+                    sh_kv2[is_k ? 0 : 1][FUSED ? lane : 0] = f32_to_bf16(a);
+                    sh_kv2[is_k ? 0 : 1][FUSED ? lane + half : 0] = f32_to_bf16(b);
+                } else {
                     bf16_t* o = (is_k ? kc : vc) + (((int64_t)slot * kv_heads + kh) * max_pos + hi) * D;
                     const bf16_t ra = f32_to_bf16(a), rb = f32_to_bf16(b);
                     o[lane] = ra;
@@ -165,6 +176,9 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
                 if (p == hi) {
                     kk[u] = *reinterpret_cast<const u4_t*>(&sh_kv[0][FUSED ? sub * 8 : 0]);
                     vv[u] = *reinterpret_cast<const u4_t*>(&sh_kv[1][FUSED ? sub * 8 : 0]);
+                } else if (partner && p == hi - 1) {
+                    kk[u] = *reinterpret_cast<const u4_t*>(&sh_kv2[0][FUSED ? sub * 8 : 0]);
+                    vv[u] = *reinterpret_cast<const u4_t*>(&sh_kv2[1][FUSED ? sub * 8 : 0]);
                 } else if (p > pre_last && p < hi) {
                     const int64_t po = (int64_t)p * D + (p < prefix_len ? pdelta : 0);
                     kk[u] = *reinterpret_cast<const u4_t*>(kb + po);
@@ -250,15 +264,15 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
 }
 
 struct FusedArgs { const float *qw, *kw, *cosT, *sinT; float eps; const int32_t* frame_ptr; int out_tiled; int prefix_slot, prefix_len;
-                   const bf16_t *kc_lo = nullptr, *vc_lo = nullptr; float* out_f32 = nullptr; int slot_base = 0; };
+                   const bf16_t *kc_lo = nullptr, *vc_lo = nullptr; float* out_f32 = nullptr; int slot_base = 0; int pair_n = 0; };
 
 template <int D, bool FUSED, int NW, bool LO = false>
 int dispatch_rep(rt_ctx* ctx, int rep, dim3 grid, const float* q, int heads, int kv_heads, const int32_t* rs, const int32_t* rp,
                  int pos_add, int window, bf16_t* kc, bf16_t* vc, int max_pos, bf16_t* out, const FusedArgs& f) {
     switch (rep) {
-        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
-        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
-        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base); break;
+        case 1: hipLaunchKernelGGL((k_attention<D, 1, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base, f.pair_n); break;
+        case 2: hipLaunchKernelGGL((k_attention<D, 2, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base, f.pair_n); break;
+        case 4: hipLaunchKernelGGL((k_attention<D, 4, FUSED, NW, LO>), grid, dim3(NW * 64), 0, ctx->stream, q, heads, kv_heads, rs, rp, pos_add, window, kc, vc, max_pos, out, f.qw, f.kw, f.eps, f.cosT, f.sinT, f.frame_ptr, f.out_tiled, f.prefix_slot, f.prefix_len, f.kc_lo, f.vc_lo, f.out_f32, f.slot_base, f.pair_n); break;
         default: return rt_fail(ctx, RT_ERR_UNSUPPORTED, "attention: heads/kv_heads = %d unsupported (1, 2, 4)", rep);
     }
     RT_HIP(ctx, hipGetLastError());
@@ -325,12 +339,15 @@ int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr, int out_tiled, int slot_base) {
+                           const int32_t* frame_ptr, int out_tiled, int slot_base, int pair_n) {
     if (!row_slot && (slot_base < 0 || slot_base + M > kv.slots))
         return rt_fail(ctx, RT_ERR_INVALID, "attention: rows %d..%d without a slot array do not fit the %d cache slots", slot_base, slot_base + M - 1, kv.slots);
-    if (row_slot && row_pos && attention_mfma_ok(M, heads, kv_heads, head_dim, window, kv))
+    // pair_n: rows [pair_n, 2 pair_n) of the launch sit one position behind rows [0, pair_n) of the same slots (see the kernel)
+    if (pair_n && (pair_n < 0 || M != 2 * pair_n || !row_slot || !row_pos || heads % kv_heads || heads / kv_heads > 2))
+        return rt_fail(ctx, RT_ERR_INVALID, "attention: paired rows need M = 2 x %d rows with slot and position arrays and <= 2 query heads per kv head", pair_n);
+    if (!pair_n && row_slot && row_pos && attention_mfma_ok(M, heads, kv_heads, head_dim, window, kv))
         return launch_attention_prefix_mfma(ctx, qkv, M, heads, kv_heads, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, row_slot, row_pos, pos_add, kv, layer,
                                             out, frame_ptr, out_tiled);
-    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr, slot_base};
+    FusedArgs f{q_norm_w, k_norm_w, rope_cos, rope_sin, eps, frame_ptr, out_tiled, -1, 0, nullptr, nullptr, nullptr, slot_base, pair_n};
     return attention_any<true>(ctx, qkv, M, heads, kv_heads, head_dim, row_slot, row_pos, pos_add, window, kv, layer, out, f);
 }

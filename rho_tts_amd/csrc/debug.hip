@@ -303,6 +303,7 @@ int rt_debug_tune(int32_t skinny_variant, int32_t skinny_waves_per_cu) {
     // flight keeps the plan it began with - the switch is refused rather than applied under it
     std::unique_lock<std::shared_mutex> all(g_tune_mu);
     if (g_runs_in_flight.load() > 0) return RT_ERR_STATE;
+    if (skinny_variant >= 2800) { g_pair_attn = skinny_variant - 2800; return RT_OK; }              // 2800/2801: the predictor's two-position first pass with k_qkv_post + attention / on the fused attention
     if (skinny_variant >= 2700) { g_frame_inc_fold = skinny_variant - 2700; return RT_OK; }         // 2700/2701: frame += 1 as a launch of its own / by the last workgroup of the talker-input launch
     if (skinny_variant >= 2600) { g_conv_unroll = skinny_variant - 2600; return RT_OK; }            // 2600/2601: k = 7 convs on the generic / the tap-unrolled k_conv_win
     if (skinny_variant >= 2400) { g_col_silu_x = skinny_variant - 2400; return RT_OK; }            // 2400/2401: gate/up decode GEMM as pairs in 1.5 rounds / as one round of 1.5-pair workgroups

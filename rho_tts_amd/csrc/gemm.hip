@@ -1024,6 +1024,7 @@ int launch_pack_weight(rt_ctx* ctx, const bf16_t* d_src, int N, int K, bf16_t* d
 rt_knob g_pred_nt{0};              // predictor weights: 0 = cacheable loads (Infinity-Cache resident across its 15 passes), 1 = non-temporal
 rt_knob g_use_graph{1};            // 1: the decode frame is replayed from captured hipGraphs
 rt_knob g_col_rows64{1};           // 1: one 64-row decode GEMM launch for the predictor's two-position pass, 0: two 32-row launches
+rt_knob g_pair_attn{1};            // 1: two-position decode passes append both positions inside the fused attention launch, 0: k_qkv_post + k_attention (rt_debug_tune 2800/2801)
 rt_knob g_frame_inc_fold{0};       // 1: frame += 1 by the last workgroup of the frame's talker-input launch, 0: k_frame_inc (rt_debug_tune 2700/2701; the fold measured 1-1.8 ms per step SLOWER)
 rt_knob g_fuse_sample_embed{1};    // 1: sampler + next-input embedding in one launch (predictor groups), 0: separate k_embed_rowsq
 rt_knob g_prefill_fill{3};          // workgroups per CU a prefill GEMM's split-K aims for

@@ -97,6 +97,7 @@ extern rt_knob g_conv_unroll;         // 1: tap-unrolled k = 7 conv kernels
 extern rt_knob g_final_conv;           // 1: dedicated last-conv kernel, 0: one-column GEMM
 extern rt_knob g_xcd_order;
 extern rt_knob g_prefill_fill;         // prefill GEMMs split K until the grid holds this many workgroups per CU
+extern rt_knob g_pair_attn;            // 1: the predictor's two-position first pass on the fused attention (no k_qkv_post launch per layer)
 extern rt_knob g_frame_inc_fold;       // 1: the talker-input launch of a frame advances the frame counter (no k_frame_inc launch)
 extern rt_knob g_fuse_sample_embed;    // 1: the predictor's sampler writes the next pass's input itself (no gather launch)
 extern rt_knob g_col_rows64;          // 1: decode GEMM launches take up to 64 rows (4 sub-blocks), 0: 32-row launches only
@@ -216,7 +217,8 @@ int launch_attention(rt_ctx* ctx, const float* q, int M, int heads, int kv_heads
 int launch_attention_fused(rt_ctx* ctx, const float* qkv, int M, int heads, int kv_heads, int head_dim, const float* q_norm_w,
                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, const int32_t* row_slot,
                            const int32_t* row_pos, int pos_add, int window, const KvCache& kv, int layer, bf16_t* out,
-                           const int32_t* frame_ptr = nullptr, int out_tiled = 0, int slot_base = -1);   // row_slot == nullptr: slot = slot_base + row; row_pos == nullptr: every row at pos_add
+                           const int32_t* frame_ptr = nullptr, int out_tiled = 0, int slot_base = -1,    // row_slot == nullptr: slot = slot_base + row; row_pos == nullptr: every row at pos_add
+                           int pair_n = 0);   // > 0: rows [pair_n, 2 pair_n) sit one position behind rows [0, pair_n) of the same slots, appended by this launch
 
 // decode attention with the shared prefix on the matrix cores (attention_mfma.hip): same contract as launch_attention_fused for
 // head_dim 128, 2 query heads per kv head, no window, a shared prefix of >= 64 rows with its transposed V copy in place

@@ -208,6 +208,11 @@ int stack_decode(rt_model* m, StackW& S, DecWs& w, float* x, float* rowsq, int M
             //  position arrays, i.e. no dependent scalar loads in front of its K / V requests)
             RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, slot_base >= 0 ? nullptr : row_slot,
                                           zero_pos ? nullptr : row_pos, pos_add, S.window, S.kv, i, w.ao, frame_ptr, 1, slot_base));
+        } else if (g_pair_attn && M % 2 == 0 && d.heads <= 2 * d.kv_heads && d.heads % d.kv_heads == 0 && row_slot && row_pos) {
+            // the two-position pass (rows [0, M/2) at one position, rows [M/2, M) of the same slots at the next): the fused launch,
+            // each second-position workgroup working out its partner's K / V itself (attention.hip, pair_n)
+            RT_TRY(launch_attention_fused(ctx, w.qkv, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos, pos_add,
+                                          S.window, S.kv, i, w.ao, frame_ptr, 1, -1, M / 2));
         } else {
             RT_TRY(launch_qkv_post(ctx, w.qkv, 1, M, d.heads, d.kv_heads, d.head_dim, L.qn, L.kn, d.rms_eps, S.cos, S.sin, row_slot, row_pos,
                                    pos_add, w.q, S.kv, i, frame_ptr));

@@ -227,6 +227,14 @@ def test_decode_lanes_and_tile_split_do_not_change_results(ctx):
         assert all(torch.equal(a, b) for a, b in zip(base, inc))
         for key in ("talker", "predictor"):
             assert torch.equal(tr0[key], tr_inc[key])
+        try:        # two-position first pass of the predictor: q/k norm + RoPE + append as their own launch (2800) == inside the fused attention (2801, default)
+            lib.rt_debug_tune(2800, 0)
+            two_l, tr_2l = nm.generate(texts, frames, sp, seed=77, trace=True)
+        finally:
+            lib.rt_debug_tune(2801, 0)
+        assert all(torch.equal(a, b) for a, b in zip(base, two_l))
+        for key in ("talker", "predictor"):
+            assert torch.equal(tr0[key], tr_2l[key])
         outs = {}
         try:
             for code in (501, 502, 504):
