@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const float* __restrict__
     int lo = 0;
     if (window > 0 && hi - window + 1 > 0) lo = hi - window + 1;
     const float scale = rsqrtf((float)D);
-    const bool partner = FUSED && pair_n > 0 && row >= pair_n;
+    const bool partner = FUSED && pair_n > 0 && row >= pair_n && hi >= 1;     // (hi >= 1: a position-0 row has nothing in front of it)
     const int64_t base = ((int64_t)slot * kv_heads + kh) * max_pos;
     const bf16_t* kb = kc + base * D + sub * 8;
     const bf16_t* vb = vc + base * D + sub * 8;
