@@ -22,6 +22,33 @@ __global__ void k_bench_barrier(unsigned* bar, int n, float* buf) {
     }
     buf[i] = acc;
 }
+// Pair hand-off ping-pong (rt_bench_grid_barrier modes 3 / 4): workgroups b and b ^ P (P = 1: neighbours in launch order, i.e. two
+// XCDs; P = 8: the same XCD) pass 2 KB and a flag back and forth, n times - what ONE workgroup-to-workgroup hand-off costs when a
+// K-split pair of a decode GEMM would add its halves in a fixed order.  flags[b] counts what b has published.
+template <int P>
+__global__ void k_bench_pair(unsigned* flags, int n, float* buf, unsigned* bar) {
+    const int b = blockIdx.x, mate = b ^ P, t = threadIdx.x;
+    float* mine = buf + (size_t)b * 512;
+    const float* theirs = buf + (size_t)mate * 512;
+    const bool first = (b & P) == 0;
+    for (int e = 1; e <= n; ++e) {
+        const bool give = first == ((e & 1) == 1);          // odd rounds: the lower workgroup gives, even rounds: the upper one
+        if (give) {
+            if (t < 512) st_agent(mine + t, (float)e);
+            __syncthreads();
+            if (t == 0) __hip_atomic_store(flags + b * 32, (unsigned)e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (t == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(flags + mate * 32, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)e)
+                    if (++spins > (1u << 22)) { bar[1] = 1u; break; }
+            }
+            __syncthreads();
+            if (bar[1]) return;                              // (spin bound hit somewhere: everybody leaves)
+            if (t < 512 && ld_agent(theirs + t) != (float)e) bar[2] = 1u;
+        }
+    }
+}
 __global__ void k_iota64(int64_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
@@ -590,12 +617,15 @@ int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int per_cu = 0;
     auto kern = mode == 2 ? k_bench_barrier<2> : (mode == 1 ? k_bench_barrier<1> : k_bench_barrier<0>);
+    if (mode >= 3 && (threads < 512 || wgs % 16)) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_grid_barrier: the pair modes take >= 512 threads and a multiple of 16 workgroups");
     RT_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0));
     if ((int64_t)per_cu * ctx->n_cu < wgs) return rt_fail(ctx, RT_ERR_INVALID, "rt_bench_grid_barrier: %d workgroups cannot be co-resident (%d per CU x %d CUs)", wgs, per_cu, ctx->n_cu);
     unsigned* bar = nullptr;
     float* buf = nullptr;
+    unsigned* flags = nullptr;
     RT_HIP(ctx, hipMalloc((void**)&bar, 64));
     RT_HIP(ctx, hipMalloc((void**)&buf, (size_t)wgs * threads * 4));
+    RT_HIP(ctx, hipMalloc((void**)&flags, (size_t)wgs * 128));
     RT_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)wgs * threads * 4, ctx->stream));
     hipEvent_t e0, e1;
     RT_HIP(ctx, hipEventCreate(&e0));
@@ -605,7 +635,10 @@ int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, 
         RT_HIP(ctx, hipMemsetAsync(bar, 0, 64, ctx->stream));
         RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
         RT_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)wgs * threads * 4, ctx->stream));
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, ctx->stream, bar, n, buf);
+        RT_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)wgs * 128, ctx->stream));
+        if (mode == 3) hipLaunchKernelGGL(k_bench_pair<1>, dim3(wgs), dim3(threads), 0, ctx->stream, flags, n, buf, bar);
+        else if (mode == 4) hipLaunchKernelGGL(k_bench_pair<8>, dim3(wgs), dim3(threads), 0, ctx->stream, flags, n, buf, bar);
+        else hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, ctx->stream, bar, n, buf);
         RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
@@ -615,7 +648,7 @@ int rt_bench_grid_barrier(rt_ctx* ctx, int32_t wgs, int32_t threads, int32_t n, 
     if (aborted) *aborted = (int32_t)(h[1] | (h[2] << 1));     // bit 0: spin bound hit, bit 1: a stale value was read
     *us_per_barrier = (double)ms * 1e3 / n;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(bar); (void)hipFree(buf);
+    (void)hipFree(bar); (void)hipFree(buf); (void)hipFree(flags);
     return RT_OK;
 }
 
